@@ -1,0 +1,347 @@
+/*
+ * fxref_fec.c -- CPU ORACLE (test infrastructure; see fxref.h).  PARITY UNPINNED.
+ *
+ * Packet coding chain behind qpacketmodem_decode / packetizer_decode, which liquid's
+ * flexframesync runs on the header and on the payload ([RECALLED liquid-dsp v1.3.x packetizer.c,
+ * interleaver.c, crc.c, scramble.c, fec_conv.c + libfec viterbi27, fec_hamming84.c,
+ * fec_secded7264.c]; reached from /root/reference/lib/flex_rx_impl.cc:213).  The FEC / CRC menu
+ * the reference selects from is at /root/reference/lib/flex_tx_impl.cc:52,118-181 and
+ * /root/reference/lib/flex_rx_impl.cc:74-136.
+ *
+ * Restatement notes (all inside "parity unpinned"):
+ *  - CRCs are the clean reflected forms (register masked to its width); liquid keeps a 32-bit
+ *    register for the 8/16/24-bit keys.
+ *  - Hamming(8,4) and SECDED(72,64) use textbook constructions (systematic extended Hamming;
+ *    Hsiao odd-weight columns), not liquid's literal generator tables, which are not recalled.
+ *  - Viterbi: K=7 (0x6d,0x4f), hard decisions, Hamming branch metric, punctured positions cost 0,
+ *    ties keep the lower predecessor, traceback from state 0.  libfec's 8-bit soft metric on
+ *    0/255 inputs selects the same path except on exact metric ties.
+ */
+#include "fxref.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+/* ---------------------------------------------------------------- CRC / checksum */
+unsigned fxr_crc_len(int check)
+{
+    switch (check) {
+    case FXR_CRC_NONE: return 0;
+    case FXR_CRC_CHECKSUM: case FXR_CRC_8: return 1;
+    case FXR_CRC_16: return 2;
+    case FXR_CRC_24: return 3;
+    case FXR_CRC_32: return 4;
+    default: return 0;
+    }
+}
+
+static uint32_t bitrev(uint32_t v, unsigned w)
+{
+    uint32_t r = 0;
+    for (unsigned i = 0; i < w; i++) if (v & (1u << i)) r |= 1u << (w - 1 - i);
+    return r;
+}
+
+static uint32_t crc_reflected(uint32_t poly, unsigned w, const uint8_t *msg, unsigned n)
+{
+    uint32_t mask = w == 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+    uint32_t p = bitrev(poly, w), key = mask;
+    for (unsigned i = 0; i < n; i++) {
+        key ^= msg[i];
+        for (int j = 0; j < 8; j++) key = (key >> 1) ^ (p & (0u - (key & 1u)));
+    }
+    return (~key) & mask;
+}
+
+uint32_t fxr_crc_key(int check, const uint8_t *msg, unsigned n)
+{
+    switch (check) {
+    case FXR_CRC_CHECKSUM: { uint32_t s = 0; for (unsigned i = 0; i < n; i++) s += msg[i]; return (~s + 1u) & 0xff; }
+    case FXR_CRC_8:  return crc_reflected(0x07, 8, msg, n);
+    case FXR_CRC_16: return crc_reflected(0x8005, 16, msg, n);
+    case FXR_CRC_24: return crc_reflected(0x5D6DCB, 24, msg, n);
+    case FXR_CRC_32: return crc_reflected(0x04C11DB7, 32, msg, n);
+    default: return 0;
+    }
+}
+
+/* ---------------------------------------------------------------- whitening */
+void fxr_scramble(uint8_t *x, unsigned n)
+{
+    static const uint8_t m[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
+    for (unsigned i = 0; i < n; i++) x[i] ^= m[i & 3];
+}
+
+/* ---------------------------------------------------------------- interleaver (depth 4) */
+static void ilv_dims(unsigned n, unsigned *M, unsigned *N)
+{
+    *M = 1 + (unsigned)floorf(sqrtf((float)n));
+    *N = n / *M;
+    while (n >= (*M) * (*N)) (*N)++;
+}
+
+/* one pass of disjoint swaps between even bytes 2i and odd bytes 2j+1 under a bit mask */
+static void ilv_pass(uint8_t *x, unsigned n, unsigned M, unsigned N, uint8_t mask)
+{
+    unsigned m = 0, nn = n / 3, n2 = n / 2, j;
+    for (unsigned i = 0; i < n2; i++) {
+        do {
+            j = m * N + nn;
+            m++;
+            if (m == M) { nn = (nn + 1) % N; m = 0; }
+        } while (j >= n2);
+        uint8_t a = x[2 * i], b = x[2 * j + 1];
+        x[2 * i]     = (uint8_t)((a & ~mask) | (b & mask));
+        x[2 * j + 1] = (uint8_t)((a & mask) | (b & ~mask));
+    }
+}
+
+void fxr_interleave(uint8_t *x, unsigned n, int decode)
+{
+    unsigned M, N; ilv_dims(n, &M, &N);
+    if (!decode) {
+        ilv_pass(x, n, M, N, 0xff);
+        ilv_pass(x, n, M, N + 2, 0x0f);
+        ilv_pass(x, n, M, N + 4, 0x55);
+        ilv_pass(x, n, M, N + 8, 0x33);
+    } else {
+        ilv_pass(x, n, M, N + 8, 0x33);
+        ilv_pass(x, n, M, N + 4, 0x55);
+        ilv_pass(x, n, M, N + 2, 0x0f);
+        ilv_pass(x, n, M, N, 0xff);
+    }
+}
+
+/* ---------------------------------------------------------------- Hamming(8,4) */
+static uint8_t h84_enc[16], h84_dec[256];
+static int h84_ready = 0;
+static void h84_init(void)
+{
+    if (h84_ready) return;
+    for (unsigned d = 0; d < 16; d++) {
+        unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
+        unsigned p0 = d0 ^ d1 ^ d3, p1 = d0 ^ d2 ^ d3, p2 = d1 ^ d2 ^ d3;
+        unsigned c = (d << 4) | (p2 << 3) | (p1 << 2) | (p0 << 1);
+        c |= (unsigned)__builtin_popcount(c) & 1u;
+        h84_enc[d] = (uint8_t)c;
+    }
+    for (unsigned r = 0; r < 256; r++) {
+        unsigned best = 0, bd = 9;
+        for (unsigned d = 0; d < 16; d++) {
+            unsigned dist = (unsigned)__builtin_popcount(r ^ h84_enc[d]);
+            if (dist < bd) { bd = dist; best = d; }
+        }
+        h84_dec[r] = (uint8_t)best;
+    }
+    h84_ready = 1;
+}
+
+/* ---------------------------------------------------------------- SECDED(72,64), Hsiao columns */
+static uint8_t sd_col[64];
+static int sd_ready = 0;
+static void sd_init(void)
+{
+    if (sd_ready) return;
+    unsigned n = 0;
+    for (unsigned v = 1; v < 256 && n < 56; v++) if (__builtin_popcount(v) == 3) sd_col[n++] = (uint8_t)v;
+    for (unsigned v = 1; v < 256 && n < 64; v++) if (__builtin_popcount(v) == 5) sd_col[n++] = (uint8_t)v;
+    sd_ready = 1;
+}
+static uint8_t sd_parity(const uint8_t d[8])
+{
+    uint8_t p = 0;
+    for (unsigned j = 0; j < 64; j++) if (d[j >> 3] & (0x80u >> (j & 7))) p ^= sd_col[j];
+    return p;
+}
+static void sd_decode_block(const uint8_t e[9], uint8_t d[8])
+{
+    memcpy(d, e + 1, 8);
+    uint8_t s = (uint8_t)(e[0] ^ sd_parity(d));
+    if (s == 0 || __builtin_popcount(s) == 1) return;   /* clean, or the parity byte took the hit */
+    for (unsigned j = 0; j < 64; j++)
+        if (sd_col[j] == s) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); return; }
+    /* double error: detected, left uncorrected */
+}
+
+/* ---------------------------------------------------------------- convolutional K=7 r=1/2 (+puncturing) */
+#define V27_A 0x6d
+#define V27_B 0x4f
+typedef struct { unsigned p; uint8_t a[8], b[8]; } punc_t;
+static const punc_t *punc_of(int fs)
+{
+    static const punc_t none = { 1, {1}, {1} };
+    static const punc_t p23  = { 2, {1,1}, {1,0} };
+    static const punc_t p34  = { 3, {1,1,0}, {1,0,1} };
+    static const punc_t p45  = { 4, {1,1,1,1}, {1,0,0,0} };
+    static const punc_t p56  = { 5, {1,1,0,1,0}, {1,0,1,0,1} };
+    static const punc_t p67  = { 6, {1,1,1,0,1,0}, {1,0,0,1,0,1} };
+    static const punc_t p78  = { 7, {1,1,1,1,0,1,0}, {1,0,0,0,1,0,1} };
+    switch (fs) {
+    case FXR_FEC_CONV_V27: return &none;
+    case FXR_FEC_CONV_V27P23: return &p23;
+    case FXR_FEC_CONV_V27P34: return &p34;
+    case FXR_FEC_CONV_V27P45: return &p45;
+    case FXR_FEC_CONV_V27P56: return &p56;
+    case FXR_FEC_CONV_V27P67: return &p67;
+    case FXR_FEC_CONV_V27P78: return &p78;
+    default: return NULL;
+    }
+}
+static inline unsigned par7(unsigned v) { return (unsigned)__builtin_popcount(v) & 1u; }
+
+static unsigned conv_enc_bits(const punc_t *pp, unsigned dec_len)
+{
+    unsigned n = 8 * dec_len + 6, bits = 0;
+    for (unsigned t = 0; t < n; t++) bits += pp->a[t % pp->p] + pp->b[t % pp->p];
+    return bits;
+}
+
+static void conv_encode(const punc_t *pp, unsigned dec_len, const uint8_t *dec, uint8_t *enc)
+{
+    unsigned n = 8 * dec_len + 6, sr = 0, nb = 0;
+    unsigned enc_len = (conv_enc_bits(pp, dec_len) + 7) / 8;
+    memset(enc, 0, enc_len);
+    for (unsigned t = 0; t < n; t++) {
+        unsigned bit = t < 8 * dec_len ? (dec[t >> 3] >> (7 - (t & 7))) & 1u : 0u;
+        sr = ((sr << 1) | bit) & 0x7f;
+        unsigned c = t % pp->p;
+        if (pp->a[c]) { if (par7(sr & V27_A)) enc[nb >> 3] |= (uint8_t)(0x80u >> (nb & 7)); nb++; }
+        if (pp->b[c]) { if (par7(sr & V27_B)) enc[nb >> 3] |= (uint8_t)(0x80u >> (nb & 7)); nb++; }
+    }
+}
+
+static void conv_decode(const punc_t *pp, unsigned dec_len, const uint8_t *enc, uint8_t *dec)
+{
+    unsigned n = 8 * dec_len + 6, nb = 0;
+    uint64_t *dw = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    uint32_t pm[64], nm[64];
+    for (int s = 0; s < 64; s++) pm[s] = 1u << 24;
+    pm[0] = 0;
+    for (unsigned t = 0; t < n; t++) {
+        unsigned c = t % pp->p;
+        int ra = -1, rb = -1;                   /* -1 = punctured (erasure) */
+        if (pp->a[c]) { ra = (enc[nb >> 3] >> (7 - (nb & 7))) & 1; nb++; }
+        if (pp->b[c]) { rb = (enc[nb >> 3] >> (7 - (nb & 7))) & 1; nb++; }
+        uint64_t d = 0;
+        for (unsigned s = 0; s < 64; s++) {
+            unsigned b = s & 1, p0 = s >> 1, p1 = p0 | 32;
+            unsigned sr0 = ((p0 << 1) | b) & 0x7f, sr1 = ((p1 << 1) | b) & 0x7f;
+            uint32_t m0 = pm[p0], m1 = pm[p1];
+            if (ra >= 0) { m0 += par7(sr0 & V27_A) != (unsigned)ra; m1 += par7(sr1 & V27_A) != (unsigned)ra; }
+            if (rb >= 0) { m0 += par7(sr0 & V27_B) != (unsigned)rb; m1 += par7(sr1 & V27_B) != (unsigned)rb; }
+            if (m1 < m0) { nm[s] = m1; d |= 1ull << s; } else nm[s] = m0;
+        }
+        memcpy(pm, nm, sizeof pm);
+        dw[t] = d;
+    }
+    memset(dec, 0, dec_len);
+    unsigned s = 0;
+    for (unsigned t = n; t-- > 0;) {
+        unsigned bit = s & 1;
+        if (t < 8 * dec_len && bit) dec[t >> 3] |= (uint8_t)(0x80u >> (t & 7));
+        s = (s >> 1) | ((unsigned)((dw[t] >> s) & 1ull) << 5);
+    }
+    free(dw);
+}
+
+/* ---------------------------------------------------------------- FEC dispatch */
+int fxr_fec_supported(int fs)
+{
+    return fs == FXR_FEC_NONE || fs == FXR_FEC_HAMMING84 || fs == FXR_FEC_SECDED7264 || punc_of(fs) != NULL;
+}
+
+unsigned fxr_fec_enc_len(int fs, unsigned n)
+{
+    const punc_t *pp = punc_of(fs);
+    if (pp) return (conv_enc_bits(pp, n) + 7) / 8;
+    switch (fs) {
+    case FXR_FEC_HAMMING84: return 2 * n;
+    case FXR_FEC_SECDED7264: return 9 * (n / 8) + ((n % 8) ? (n % 8) + 1 : 0);
+    default: return n;
+    }
+}
+
+void fxr_fec_encode(int fs, unsigned n, const uint8_t *dec, uint8_t *enc)
+{
+    const punc_t *pp = punc_of(fs);
+    if (pp) { conv_encode(pp, n, dec, enc); return; }
+    switch (fs) {
+    case FXR_FEC_HAMMING84:
+        h84_init();
+        for (unsigned i = 0; i < n; i++) { enc[2 * i] = h84_enc[dec[i] >> 4]; enc[2 * i + 1] = h84_enc[dec[i] & 15]; }
+        return;
+    case FXR_FEC_SECDED7264: {
+        sd_init();
+        unsigned i = 0, j = 0;
+        for (; i + 8 <= n; i += 8, j += 9) { enc[j] = sd_parity(dec + i); memcpy(enc + j + 1, dec + i, 8); }
+        if (n % 8) {
+            uint8_t d[8] = { 0 }; memcpy(d, dec + i, n % 8);
+            enc[j] = sd_parity(d); memcpy(enc + j + 1, d, n % 8);
+        }
+        return; }
+    default: memcpy(enc, dec, n); return;
+    }
+}
+
+void fxr_fec_decode(int fs, unsigned n, const uint8_t *enc, uint8_t *dec)
+{
+    const punc_t *pp = punc_of(fs);
+    if (pp) { conv_decode(pp, n, enc, dec); return; }
+    switch (fs) {
+    case FXR_FEC_HAMMING84:
+        h84_init();
+        for (unsigned i = 0; i < n; i++) dec[i] = (uint8_t)((h84_dec[enc[2 * i]] << 4) | h84_dec[enc[2 * i + 1]]);
+        return;
+    case FXR_FEC_SECDED7264: {
+        sd_init();
+        unsigned i = 0, j = 0;
+        for (; i + 8 <= n; i += 8, j += 9) sd_decode_block(enc + j, dec + i);
+        if (n % 8) {
+            uint8_t e[9] = { 0 }, d[8];
+            memcpy(e, enc + j, n % 8 + 1);
+            sd_decode_block(e, d);
+            memcpy(dec + i, d, n % 8);
+        }
+        return; }
+    default: memcpy(dec, enc, n); return;
+    }
+}
+
+/* ---------------------------------------------------------------- packetizer */
+unsigned fxr_packet_enc_len(unsigned n, int check, int fec0, int fec1)
+{
+    unsigned k = n + fxr_crc_len(check);
+    return fxr_fec_enc_len(fec1, fxr_fec_enc_len(fec0, k));
+}
+
+void fxr_packet_encode(unsigned n, int check, int fec0, int fec1, const uint8_t *msg, uint8_t *pkt)
+{
+    unsigned cl = fxr_crc_len(check), k = n + cl;
+    unsigned l0 = fxr_fec_enc_len(fec0, k), l1 = fxr_fec_enc_len(fec1, l0);
+    uint8_t *b0 = (uint8_t *)calloc(l1 + 16, 1), *b1 = (uint8_t *)calloc(l1 + 16, 1);
+    memcpy(b0, msg, n);
+    uint32_t key = fxr_crc_key(check, b0, n);
+    for (unsigned i = 0; i < cl; i++) { b0[n + cl - i - 1] = (uint8_t)(key & 0xff); key >>= 8; }
+    fxr_scramble(b0, k);
+    fxr_fec_encode(fec0, k, b0, b1);  fxr_interleave(b1, l0, 0);
+    fxr_fec_encode(fec1, l0, b1, b0); fxr_interleave(b0, l1, 0);
+    memcpy(pkt, b0, l1);
+    free(b0); free(b1);
+}
+
+int fxr_packet_decode(unsigned n, int check, int fec0, int fec1, const uint8_t *pkt, uint8_t *msg)
+{
+    unsigned cl = fxr_crc_len(check), k = n + cl;
+    unsigned l0 = fxr_fec_enc_len(fec0, k), l1 = fxr_fec_enc_len(fec1, l0);
+    uint8_t *b0 = (uint8_t *)calloc(l1 + 16, 1), *b1 = (uint8_t *)calloc(l1 + 16, 1);
+    memcpy(b0, pkt, l1);
+    fxr_interleave(b0, l1, 1); fxr_fec_decode(fec1, l0, b0, b1);
+    fxr_interleave(b1, l0, 1); fxr_fec_decode(fec0, k, b1, b0);
+    fxr_scramble(b0, k);
+    uint32_t key = 0;
+    for (unsigned i = 0; i < cl; i++) key = (key << 8) | b0[n + i];
+    memcpy(msg, b0, n);
+    int ok = (fxr_crc_key(check, b0, n) == key);
+    free(b0); free(b1);
+    return ok;
+}
