@@ -1,0 +1,147 @@
+"""ctypes binding of libfxrx.so (C ABI in include/fxrx.h).
+
+The library is the product: if it is missing or no HIP device is usable, constructors raise.
+There is no Python/CPU implementation of the receive path in this package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libfxrx.so")
+
+
+class FxComplex(C.Structure):
+    _fields_ = [("re", C.c_float), ("im", C.c_float)]
+
+
+class FrameSyncStats(C.Structure):          # framesyncstats_s
+    _fields_ = [("evm", C.c_float), ("rssi", C.c_float), ("cfo", C.c_float),
+                ("framesyms", C.POINTER(FxComplex)), ("num_framesyms", C.c_uint),
+                ("mod_scheme", C.c_uint), ("mod_bps", C.c_uint), ("check", C.c_uint),
+                ("fec0", C.c_uint), ("fec1", C.c_uint)]
+
+
+FRAMESYNC_CALLBACK = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_ubyte), C.c_int, C.POINTER(C.c_ubyte), C.c_uint,
+                                 C.c_int, FrameSyncStats, C.c_void_p)
+
+
+class GenProps(C.Structure):                # flexframegenprops_s
+    _fields_ = [("check", C.c_uint), ("fec0", C.c_uint), ("fec1", C.c_uint), ("mod_scheme", C.c_uint)]
+
+
+class Config(C.Structure):                  # fxrx_config
+    _fields_ = [("device", C.c_int), ("mode", C.c_int), ("n_streams", C.c_uint), ("threshold", C.c_float),
+                ("segment_len", C.c_uint), ("want_framesyms", C.c_int)]
+
+
+class Frame(C.Structure):                   # fxrx_frame
+    _fields_ = [("stream", C.c_uint), ("start", C.c_int64), ("cfo_bin", C.c_int),
+                ("rxy", C.c_float), ("tau", C.c_float), ("gamma", C.c_float), ("dphi", C.c_float), ("phi", C.c_float),
+                ("pfb_index", C.c_uint),
+                ("pilot_dphi", C.c_float), ("pilot_phi", C.c_float), ("pilot_gain", C.c_float),
+                ("header_valid", C.c_int), ("payload_valid", C.c_int),
+                ("header", C.c_ubyte * 20),
+                ("payload", C.POINTER(C.c_ubyte)), ("payload_len", C.c_uint),
+                ("framesyms", C.POINTER(FxComplex)), ("num_framesyms", C.c_uint),
+                ("evm_db", C.c_float), ("rssi_db", C.c_float), ("cfo", C.c_float), ("evm_sum", C.c_float),
+                ("mod_scheme", C.c_uint), ("mod_bps", C.c_uint), ("check", C.c_uint), ("fec0", C.c_uint), ("fec1", C.c_uint)]
+
+
+class Timing(C.Structure):                  # fxrx_timing
+    _fields_ = [("walk_ms", C.c_double), ("paymf_ms", C.c_double), ("paypll_ms", C.c_double),
+                ("paydec_ms", C.c_double), ("total_ms", C.c_double),
+                ("hops", C.c_uint64), ("walk_jobs", C.c_uint64), ("repairs", C.c_uint64),
+                ("frames", C.c_uint64), ("payload_symbols", C.c_uint64), ("samples", C.c_uint64)]
+
+
+# every symbol include/fxrx.h declares (checked by tests/test_cabi.py)
+EXPORTS = [
+    "flexframesync_create", "flexframesync_destroy", "flexframesync_execute", "flexframesync_reset",
+    "fxrx_sync_flush", "fxrx_sync_set_block", "fxrx_sync_set_threshold", "fxrx_sync_pending",
+    "msequence_create", "msequence_advance", "msequence_destroy",
+    "qdetector_cccf_create_linear", "qdetector_cccf_destroy", "qdetector_cccf_set_threshold",
+    "qdetector_cccf_execute", "qdetector_cccf_get_tau", "qdetector_cccf_get_gamma", "qdetector_cccf_get_dphi",
+    "qdetector_cccf_get_phi", "qdetector_cccf_get_buf_len",
+    "flexframegenprops_init_default", "flexframegen_create", "flexframegen_destroy", "flexframegen_setprops",
+    "flexframegen_assemble", "flexframegen_getframelen", "flexframegen_write_samples", "fxrx_gen_set_delay",
+    "fxrx_last_error", "fxrx_version", "fxrx_device_count", "fxrx_create", "fxrx_destroy", "fxrx_reset",
+    "fxrx_process", "fxrx_result", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
+    "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
+    "fxrx_outer_from_index", "fxrx_outer_to_index",
+]
+
+
+def build(force=False):
+    """Compile libfxrx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: PyTorch ships its own libamdhip64 (same SONAME as /opt/rocm's).  If torch
+    # is going to be used in this process it must be loaded first so that libfxrx.so binds to that copy;
+    # loading two runtimes leaves the second one without a device ("No HIP GPUs are available").
+    if os.environ.get("FXRX_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libfxrx.so is not built (%s); run __graft_entry__.build() -- there is no fallback path" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    L.fxrx_last_error.restype = C.c_char_p
+    L.fxrx_version.restype = C.c_char_p
+    L.fxrx_device_count.restype = C.c_int
+    L.fxrx_create.restype = C.c_void_p; L.fxrx_create.argtypes = [C.POINTER(Config)]
+    L.fxrx_destroy.argtypes = [C.c_void_p]; L.fxrx_destroy.restype = None
+    L.fxrx_reset.argtypes = [C.c_void_p]; L.fxrx_reset.restype = None
+    L.fxrx_process.restype = C.c_int
+    L.fxrx_process.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
+    L.fxrx_result.restype = C.c_int; L.fxrx_result.argtypes = [C.c_void_p, C.c_uint, C.POINTER(Frame)]
+    L.fxrx_device_framesyms.restype = C.c_void_p; L.fxrx_device_framesyms.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
+    L.fxrx_last_timing.restype = C.c_int; L.fxrx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
+    L.fxrx_stream.restype = C.c_void_p; L.fxrx_stream.argtypes = [C.c_void_p]
+    L.fxrx_gen_frame_len.restype = C.c_uint; L.fxrx_gen_frame_len.argtypes = [C.c_uint] * 5
+    for n in ("mod", "inner", "outer"):
+        f = getattr(L, "fxrx_%s_from_index" % n); f.restype = C.c_int; f.argtypes = [C.c_int]
+        f = getattr(L, "fxrx_%s_to_index" % n); f.restype = C.c_int; f.argtypes = [C.c_uint]
+    # drop-in names
+    L.flexframesync_create.restype = C.c_void_p; L.flexframesync_create.argtypes = [FRAMESYNC_CALLBACK, C.c_void_p]
+    L.flexframesync_destroy.argtypes = [C.c_void_p]; L.flexframesync_destroy.restype = None
+    L.flexframesync_reset.argtypes = [C.c_void_p]; L.flexframesync_reset.restype = None
+    L.flexframesync_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]; L.flexframesync_execute.restype = None
+    L.fxrx_sync_flush.argtypes = [C.c_void_p]; L.fxrx_sync_flush.restype = None
+    L.fxrx_sync_set_block.argtypes = [C.c_void_p, C.c_uint]; L.fxrx_sync_set_block.restype = None
+    L.fxrx_sync_set_threshold.argtypes = [C.c_void_p, C.c_float]; L.fxrx_sync_set_threshold.restype = None
+    L.fxrx_sync_pending.argtypes = [C.c_void_p]; L.fxrx_sync_pending.restype = C.c_uint
+    L.msequence_create.restype = C.c_void_p; L.msequence_create.argtypes = [C.c_uint] * 3
+    L.msequence_advance.restype = C.c_uint; L.msequence_advance.argtypes = [C.c_void_p]
+    L.msequence_destroy.argtypes = [C.c_void_p]; L.msequence_destroy.restype = None
+    L.qdetector_cccf_create_linear.restype = C.c_void_p
+    L.qdetector_cccf_create_linear.argtypes = [C.c_void_p, C.c_uint, C.c_int, C.c_uint, C.c_uint, C.c_float]
+    L.qdetector_cccf_destroy.argtypes = [C.c_void_p]; L.qdetector_cccf_destroy.restype = None
+    L.qdetector_cccf_set_threshold.argtypes = [C.c_void_p, C.c_float]; L.qdetector_cccf_set_threshold.restype = None
+    L.qdetector_cccf_execute.restype = C.c_void_p; L.qdetector_cccf_execute.argtypes = [C.c_void_p, FxComplex]
+    for n in ("tau", "gamma", "dphi", "phi"):
+        f = getattr(L, "qdetector_cccf_get_" + n); f.restype = C.c_float; f.argtypes = [C.c_void_p]
+    L.qdetector_cccf_get_buf_len.restype = C.c_uint; L.qdetector_cccf_get_buf_len.argtypes = [C.c_void_p]
+    L.flexframegenprops_init_default.argtypes = [C.POINTER(GenProps)]
+    L.flexframegen_create.restype = C.c_void_p; L.flexframegen_create.argtypes = [C.POINTER(GenProps)]
+    L.flexframegen_destroy.argtypes = [C.c_void_p]; L.flexframegen_destroy.restype = None
+    L.flexframegen_setprops.argtypes = [C.c_void_p, C.POINTER(GenProps)]
+    L.flexframegen_assemble.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint]
+    L.flexframegen_getframelen.restype = C.c_uint; L.flexframegen_getframelen.argtypes = [C.c_void_p]
+    L.flexframegen_write_samples.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+    L.fxrx_gen_set_delay.argtypes = [C.c_void_p, C.c_float]; L.fxrx_gen_set_delay.restype = None
+    _lib = L
+    return L

@@ -1,0 +1,124 @@
+// fx_common.h -- constants and plain-data records shared by host code and HIP kernels.
+//
+// Frame geometry of liquid-dsp's flexframe as used by gr::liquiddsp::flex_rx / frame_detector_cc
+// (reference parameters: /root/reference/lib/frame_detector_cc_impl.h:34-36,
+// /root/reference/lib/frame_detector_cc_impl.cc:46-55, /root/reference/lib/flex_tx_impl.cc:52,58).
+#pragma once
+#include <stdint.h>
+#include <hip/hip_vector_types.h>
+
+#define FX_K             2
+#define FX_M             7
+#define FX_BETA          0.3f
+#define FX_NPFB          32
+#define FX_MF_TAPS       28
+#define FX_PROTO_LEN     897
+#define FX_PN_LEN        64
+#define FX_S_LEN         156
+#define FX_NFFT          512
+#define FX_HOP           256
+#define FX_RANGE         24
+#define FX_HDR_USER      14
+#define FX_HDR_DEC       20
+#define FX_HDR_CRC       24      /* 20 + CRC32 */
+#define FX_HDR_E0        27      /* after SECDED(72,64) */
+#define FX_HDR_ENC       54      /* after Hamming(8,4) */
+#define FX_HDR_MOD       216
+#define FX_HDR_PILOTS    15
+#define FX_HDR_SYM       231
+#define FX_PILOT_SPACING 16
+#define FX_PROTOCOL      102
+#define FX_SYM0_HDR      78      /* 2m + 64 */
+#define FX_SYM0_PAY      309
+
+// header-stored enums (liquid.h v1.3.x numbering, recalled; see include/fxrx.h)
+enum { FX_CRC_UNKNOWN = 0, FX_CRC_NONE, FX_CRC_CHECKSUM, FX_CRC_8, FX_CRC_16, FX_CRC_24, FX_CRC_32 };
+enum {
+    FX_FEC_UNKNOWN = 0, FX_FEC_NONE = 1, FX_FEC_HAMMING74 = 4, FX_FEC_HAMMING84 = 5, FX_FEC_HAMMING128 = 6,
+    FX_FEC_GOLAY2412 = 7, FX_FEC_SECDED2216 = 8, FX_FEC_SECDED3932 = 9, FX_FEC_SECDED7264 = 10,
+    FX_FEC_CONV_V27 = 11, FX_FEC_CONV_V27P23 = 15, FX_FEC_CONV_V27P34 = 16, FX_FEC_CONV_V27P45 = 17,
+    FX_FEC_CONV_V27P56 = 18, FX_FEC_CONV_V27P67 = 19, FX_FEC_CONV_V27P78 = 20, FX_FEC_RS_M8 = 27
+};
+enum {
+    FX_MODEM_UNKNOWN = 0, FX_MODEM_PSK2 = 1, FX_MODEM_PSK4 = 2, FX_MODEM_PSK8 = 3, FX_MODEM_PSK16 = 4,
+    FX_MODEM_DPSK2 = 9, FX_MODEM_DPSK4 = 10, FX_MODEM_DPSK8 = 11, FX_MODEM_ASK4 = 18,
+    FX_MODEM_QAM16 = 27, FX_MODEM_QAM32 = 28, FX_MODEM_QAM64 = 29, FX_MODEM_QPSK = 40
+};
+
+// ---- walker job / result records (device memory, written by fx_walk_kernel) ----
+enum { FX_MODE_FLEXRX = 0, FX_MODE_DETECT = 1 };
+enum {
+    FX_EXIT_STOP = 0,        // reached job.stop, hand-off target recorded (or not requested)
+    FX_EXIT_NEED_DATA = 1,   // ran out of samples in SEEK/ALIGN/header: resume at (pos, fresh, floor)
+    FX_EXIT_PAYLOAD = 2,     // last frame descriptor is incomplete: payload runs past the end of data
+    FX_EXIT_TABLE_FULL = 3   // frame table exhausted: resume at (pos, fresh, floor)
+};
+enum { FX_FLAG_HEADER_VALID = 1, FX_FLAG_INCOMPLETE = 2, FX_FLAG_EXACT = 4 /* walker was in exact (locked) mode */ };
+
+struct FxWalkJob {
+    const float2 *x;        // stream samples; logical index 0 == x[0]
+    int64_t  n;             // samples available
+    int64_t  start;         // first new-half position (detector restarts / resumes here)
+    int64_t  stop;          // segment end: no new detection is *started* at pos >= stop
+    int64_t  floor;         // samples below this index read as zero (last synchroniser reset)
+    uint32_t fresh;         // 1: overlap half is zeros (just reset); 0: overlap = x[start-256, start)
+    uint32_t mode;          // FX_MODE_*
+    uint32_t handoff;       // 1: past stop, keep seeking until the next detection and record it
+    uint32_t prelock;       // 1: speculative start: anything found before the first trustworthy frame is
+                            //    tentative (see fx_host.cpp); 0: state is the true sequential state
+    uint32_t frame_base;    // first slot of this job in the frame table
+    uint32_t max_frames;    // slots available
+    float    threshold;
+};
+
+struct FxFrame {            // 128 bytes
+    int64_t  start;         // index of aligned sample 0 (may be < floor: zeros there)
+    int64_t  next;          // restart position after this frame (flex_rx) / next new-half (detect)
+    int32_t  offset;        // CFO bin of the coarse search
+    float    rxy, tau, gamma, dphi, phi;
+    uint32_t pfb; int32_t mfc0;
+    uint32_t mix_th, mix_dl; float mf_scale;
+    float    pilot_dphi, pilot_phi, pilot_gain;
+    uint32_t pll_th; float pll_f;
+    uint32_t flags;
+    uint32_t pay_len, ms, check, fec0, fec1, pay_sym_len;
+    uint8_t  header[FX_HDR_DEC];
+};
+
+struct FxWalkResult {
+    uint32_t n_frames;      // descriptors written
+    uint32_t exit_code;     // FX_EXIT_*
+    int64_t  pos;           // resume position (new-half start)
+    int64_t  floor;
+    uint32_t fresh;
+    uint32_t has_handoff;   // hand-off target valid
+    int64_t  handoff_start; int32_t handoff_offset; uint32_t hops;
+    float    handoff_rxy; uint32_t pad_;
+};
+
+// ---- payload stage records ----
+struct FxPayJob {           // one per valid, complete frame
+    const float2 *x;        // stream base
+    int64_t  start;         // aligned sample 0
+    uint32_t mix_th, mix_dl; float mf_scale;
+    uint32_t pfb; int32_t mfc0;
+    uint32_t pll_th; float pll_f;
+    uint32_t ms, bps;
+    uint32_t nsym;          // payload symbols
+    uint32_t sym_off;       // offset (symbols) of this frame in the symbol arenas
+    // decode plan
+    uint32_t pay_len, check, fec0, fec1;
+    uint32_t k;             // pay_len + crc_len
+    uint32_t l0, l1;        // bytes after fec0 / after fec1
+    uint32_t perm0_off, perm1_off;   // offsets into the permutation arena (bit gather tables)
+    uint32_t byte_off;      // offset of this frame's scratch in the byte arenas (stride >= l1+8)
+    uint32_t dw_off;        // offset in the decision-word arena (u64 units)
+    uint32_t out_off;       // offset of decoded payload in the output arena
+};
+
+struct FxPayResult {
+    float    evm_sum;
+    uint32_t payload_valid;
+    uint32_t status;        // 0 ok, 1 unsupported FEC on device
+    uint32_t pad_;
+};

@@ -1,0 +1,284 @@
+// fx_device.h -- device-side arithmetic primitives for the flexframe RX kernels (gfx950, wave64).
+//
+// Every function here follows the canonical arithmetic written down in DESIGN.md §4: IEEE binary32,
+// no contraction (-ffp-contract=off) except where fmaf() is spelled out, no libm transcendental on
+// path data, fixed reduction orders.  That is what lets detection indices, polyphase-branch picks and
+// hard decisions come out identical to a scalar CPU run of the same algorithm.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "fx_common.h"
+
+struct FxTables {
+    float2   tw[512];        // exp(-j 2 pi m / 512)
+    float2   sc[1024];       // (cos, sin)(2 pi k / 1024)
+    float2   S[512];         // FFT of the zero-padded detector template
+    float2   s[FX_S_LEN];    // detector template (RRC-shaped p/n preamble)
+    float2   pilots[16];
+    float    proto[FX_PROTO_LEN + 3];
+    float    s2sum;          // sum |s|^2
+    float    pad_[3];
+    uint16_t perm54[FX_HDR_ENC * 8];   // bit gather tables of the header de-interleavers
+    uint16_t perm27[FX_HDR_E0 * 8];
+    uint8_t  h84dec[256];
+    uint8_t  sdcol[64];
+};
+
+#define FX_DEV __device__ __forceinline__
+
+FX_DEV float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+FX_DEV float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+// a * w
+FX_DEV float2 cmul(float2 a, float2 w)
+{
+    float t = a.y * w.y, u = a.y * w.x;
+    return make_float2(fmaf(a.x, w.x, -t), fmaf(a.x, w.y, u));
+}
+// a * conj(b)
+FX_DEV float2 cmulc(float2 a, float2 b)
+{
+    float t = a.y * b.y, u = a.x * b.y;
+    return make_float2(fmaf(a.x, b.x, t), fmaf(a.y, b.x, -u));
+}
+FX_DEV float cm2(float2 a) { return fmaf(a.x, a.x, a.y * a.y); }
+
+FX_DEV uint32_t rad2u32(float rad)
+{
+    float t = rintf(rad * 683565248.0f);
+    return (uint32_t)(long long)t;
+}
+
+FX_DEV void sincos_u32(uint32_t th, const float2 *sc, float &c, float &s)
+{
+    const float2 t = sc[th >> 22];
+    float d  = (float)(th & 0x3FFFFFu) * 1.4629180792671596e-9f;
+    float d2 = d * d;
+    float cd = fmaf(d2, -0.5f, 1.0f);
+    float sd = fmaf(d2 * d, -0.16666667f, d);
+    c = fmaf(t.x, cd, -(t.y * sd));
+    s = fmaf(t.y, cd, t.x * sd);
+}
+
+// x * exp(-j theta)
+FX_DEV float2 derot(float2 x, uint32_t th, const float2 *sc)
+{
+    float c, s; sincos_u32(th, sc, c, s);
+    return make_float2(fmaf(x.x, c, x.y * s), fmaf(x.y, c, -(x.x * s)));
+}
+
+FX_DEV float atan2c(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float base = 0.0f;
+    if (a > 0.41421356f) { a = (a - 1.0f) / (a + 1.0f); base = 0.78539816f; }
+    float z = a * a;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    float r = fmaf(p * z, a, a) + base;
+    if (ay > ax) r = 1.57079633f - r;
+    if (x < 0.0f) r = 3.14159265f - r;
+    return y < 0.0f ? -r : r;
+}
+
+// ---------------------------------------------------------------- 8-point DFT in registers
+#define FX_C8 0.70710678118654752f
+FX_DEV void dft4(float2 c0, float2 c1, float2 c2, float2 c3, float2 &o0, float2 &o1, float2 &o2, float2 &o3)
+{
+    float2 d0 = cadd(c0, c2), d1 = cadd(c1, c3), d2 = csub(c0, c2), e = csub(c1, c3);
+    float2 d3 = make_float2(e.y, -e.x);
+    o0 = cadd(d0, d1); o2 = csub(d0, d1);
+    o1 = cadd(d2, d3); o3 = csub(d2, d3);
+}
+FX_DEV void dft8(float2 a[8])
+{
+    float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+    float2 b1 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]);
+    float2 b2 = cadd(a[2], a[6]), t6 = csub(a[2], a[6]);
+    float2 b3 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
+    float2 b5 = make_float2((t5.x + t5.y) * FX_C8, (t5.y - t5.x) * FX_C8);
+    float2 b6 = make_float2(t6.y, -t6.x);
+    float2 b7 = make_float2((t7.y - t7.x) * FX_C8, -((t7.x + t7.y) * FX_C8));
+    dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+    dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+}
+
+// ---------------------------------------------------------------- FFT-512 by one wavefront
+// In : lane j holds a[q] = x[j + 64 q].          (decimation in frequency, 8 x 8 x 8)
+// Out: lane L holds a[t] = X[(L>>3) + 8 (L&7) + 64 t].
+// scr: 576 float2 of LDS private to the wave (8 rows of 72: 64 data + 8 pad, conflict-free for
+//      both ds_write_b64 and ds_read_b64 in either exchange).
+// twA[r-1] = W512^(lane r), twB[s-1] = W512^(8 (lane&7) s), r,s = 1..7.
+FX_DEV void fft512_wave(float2 a[8], float2 *scr, int lane, const float2 twA[7], const float2 twB[7])
+{
+    dft8(a);
+#pragma unroll
+    for (int r = 1; r < 8; r++) a[r] = cmul(a[r], twA[r - 1]);
+#pragma unroll
+    for (int r = 0; r < 8; r++) scr[r * 72 + lane] = a[r];
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int r = lane >> 3, j0 = lane & 7;
+#pragma unroll
+        for (int p = 0; p < 8; p++) a[p] = scr[r * 72 + j0 + 8 * p];
+        __builtin_amdgcn_wave_barrier();
+        dft8(a);
+#pragma unroll
+        for (int s = 1; s < 8; s++) a[s] = cmul(a[s], twB[s - 1]);
+#pragma unroll
+        for (int s = 0; s < 8; s++) scr[r * 72 + s * 9 + j0] = a[s];
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int r = lane >> 3, s = lane & 7;
+#pragma unroll
+        for (int j0 = 0; j0 < 8; j0++) a[j0] = scr[r * 72 + s * 9 + j0];
+        __builtin_amdgcn_wave_barrier();
+        dft8(a);
+    }
+}
+
+// balanced-tree sum across the 64 lanes (xor butterfly; a+b is commutative bit-for-bit)
+FX_DEV float wave_sum(float v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// argmax with "first maximum in key order wins": returns the pair on all lanes
+FX_DEV void wave_argmax(float &v, uint32_t &key)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        float ov = __shfl_xor(v, m, 64);
+        uint32_t ok = __shfl_xor(key, m, 64);
+        bool take = (ov > v) || (ov == v && ok < key);
+        v = take ? ov : v; key = take ? ok : key;
+    }
+}
+
+// ---------------------------------------------------------------- modem (hard decision + phase error)
+FX_DEV unsigned gray_enc(unsigned x) { return x ^ (x >> 1); }
+
+FX_DEV unsigned modem_bps(unsigned ms)
+{
+    switch (ms) {
+    case FX_MODEM_PSK2: case FX_MODEM_DPSK2: return 1;
+    case FX_MODEM_PSK4: case FX_MODEM_DPSK4: case FX_MODEM_ASK4: case FX_MODEM_QPSK: return 2;
+    case FX_MODEM_PSK8: case FX_MODEM_DPSK8: return 3;
+    case FX_MODEM_PSK16: case FX_MODEM_QAM16: return 4;
+    case FX_MODEM_QAM32: return 5;
+    case FX_MODEM_QAM64: return 6;
+    default: return 0;
+    }
+}
+
+FX_DEV unsigned pam_index(float v, float inv2al, unsigned Lv)
+{
+    float t = floorf(fmaf(v, inv2al, 0.5f * (float)Lv));
+    if (t < 0.0f) t = 0.0f;
+    if (t > (float)(Lv - 1)) t = (float)(Lv - 1);
+    return (unsigned)t;
+}
+
+FX_DEV unsigned psk_index(float2 r, unsigned bps)
+{
+    if (bps == 1) return r.x > 0.0f ? 0u : 1u;
+    if (bps == 2) {
+        if (fabsf(r.x) >= fabsf(r.y)) return r.x > 0.0f ? 0u : 2u;
+        return r.y > 0.0f ? 1u : 3u;
+    }
+    float th = atan2c(r.y, r.x);
+    float t = rintf(th * ((float)(1u << bps) * 0.159154943f));
+    return (unsigned)((int)t) & ((1u << bps) - 1u);
+}
+
+// dpsk_prev: running phase index of differential schemes (in/out)
+FX_DEV unsigned modem_demod(unsigned ms, unsigned bps, float2 r, unsigned &dpsk_prev, const float2 *sc,
+                            float2 &xh, float &pe)
+{
+    unsigned sym;
+    switch (ms) {
+    case FX_MODEM_QPSK:
+        sym = (r.x > 0.0f ? 0u : 1u) | (r.y > 0.0f ? 0u : 2u);
+        xh = make_float2((sym & 1) ? -0.70710678118654752f : 0.70710678118654752f,
+                         (sym & 2) ? -0.70710678118654752f : 0.70710678118654752f);
+        break;
+    case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: {
+        unsigned idx = psk_index(r, bps);
+        sym = gray_enc(idx); xh = sc[(idx << (32 - bps)) >> 22];
+        break; }
+    case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8: {
+        unsigned idx = psk_index(r, bps);
+        sym = gray_enc((idx - dpsk_prev) & ((1u << bps) - 1u));
+        dpsk_prev = idx; xh = sc[(idx << (32 - bps)) >> 22];
+        break; }
+    case FX_MODEM_ASK4: {
+        unsigned idx = pam_index(r.x, 1.11803399f, 4);
+        sym = gray_enc(idx); xh = make_float2((2.0f * (float)idx - 3.0f) * 0.447213595f, 0.0f);
+        break; }
+    default: {
+        unsigned mi, mq; float al;
+        if (ms == FX_MODEM_QAM16) { mi = 2; mq = 2; al = 0.316227766f; }
+        else if (ms == FX_MODEM_QAM32) { mi = 3; mq = 2; al = 0.196116135f; }
+        else { mi = 3; mq = 3; al = 0.154303350f; }
+        float inv = 0.5f / al;
+        unsigned ii = pam_index(r.x, inv, 1u << mi), iq = pam_index(r.y, inv, 1u << mq);
+        sym = (gray_enc(ii) << mq) | gray_enc(iq);
+        xh = make_float2((2.0f * (float)ii - (float)((1u << mi) - 1u)) * al,
+                         (2.0f * (float)iq - (float)((1u << mq) - 1u)) * al);
+        break; }
+    }
+    float pr = fmaf(r.x, xh.x, r.y * xh.y);
+    float pi = fmaf(r.y, xh.x, -(r.x * xh.y));
+    pe = atan2c(pi, pr);
+    return sym;
+}
+
+// sample index (relative to the aligned start) at which MF output symbol c appears
+FX_DEV int64_t sym_sample(int64_t c, int mfc0) { return mfc0 == 0 ? 2 * c : (c == 0 ? 0 : 2 * c - 1); }
+
+// ---------------------------------------------------------------- coded lengths (device copy of the host rule)
+FX_DEV unsigned crc_len(unsigned check)
+{
+    switch (check) {
+    case FX_CRC_CHECKSUM: case FX_CRC_8: return 1;
+    case FX_CRC_16: return 2;
+    case FX_CRC_24: return 3;
+    case FX_CRC_32: return 4;
+    default: return 0;
+    }
+}
+FX_DEV int conv_p(unsigned fs)   // puncturing period; 0 = not a K=7 convolutional scheme
+{
+    switch (fs) {
+    case FX_FEC_CONV_V27: return 1;
+    case FX_FEC_CONV_V27P23: return 2;
+    case FX_FEC_CONV_V27P34: return 3;
+    case FX_FEC_CONV_V27P45: return 4;
+    case FX_FEC_CONV_V27P56: return 5;
+    case FX_FEC_CONV_V27P67: return 6;
+    case FX_FEC_CONV_V27P78: return 7;
+    default: return 0;
+    }
+}
+FX_DEV bool fec_supported(unsigned fs)
+{
+    return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || conv_p(fs) != 0;
+}
+FX_DEV unsigned fec_enc_len(unsigned fs, unsigned n)
+{
+    int p = conv_p(fs);
+    if (p) {
+        unsigned T = 8 * n + 6;
+        unsigned bits = p == 1 ? 2 * T : T + (T + (unsigned)p - 1) / (unsigned)p;
+        return (bits + 7) / 8;
+    }
+    if (fs == FX_FEC_HAMMING84) return 2 * n;
+    if (fs == FX_FEC_SECDED7264) return 9 * (n / 8) + ((n % 8) ? (n % 8) + 1 : 0);
+    return n;
+}

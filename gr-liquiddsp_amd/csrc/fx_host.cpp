@@ -1,0 +1,467 @@
+// fx_host.cpp -- host runtime of libfxrx.so: device tables, per-stream state carried across calls,
+// speculative segment walking with exact stitching, payload job planning, result marshalling and the
+// C ABI declared in include/fxrx.h.
+//
+// Why segments: liquid's synchroniser is one sequential state machine per stream (where the detector
+// restarts after a frame depends on that frame's header).  Each stream is cut into segments that are
+// walked concurrently from a freshly-reset detector; a segment's walker, once past its end, keeps
+// seeking until its next detection (a, cfo_bin) -- the hand-off target.  If the next segment's
+// speculative list contains that same (a, cfo_bin), everything after it is provably what the
+// sequential machine would have produced (frame processing depends only on the aligned start and
+// the coarse bin), so the lists are spliced; otherwise that segment is re-walked from the true state
+// ("repair").  The result is identical to a single sequential walk, for any segment size.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <memory>
+#include <mutex>
+#include <string>
+#include "../../include/fxrx.h"
+#include "fx_device.h"
+#include "fx_codec.hpp"
+
+extern "C" __global__ void fx_walk_kernel(const FxWalkJob *, FxWalkResult *, FxFrame *, const FxTables *);
+extern "C" __global__ void fx_paymf_kernel(const FxPayJob *, const uint32_t *, const uint32_t *, float2 *, const FxTables *);
+extern "C" __global__ void fx_paypll_kernel(const FxPayJob *, uint32_t, const float2 *, float2 *, uint8_t *, FxPayResult *, const FxTables *);
+extern "C" __global__ void fx_paydec_kernel(const FxPayJob *, const uint8_t *, const uint32_t *, uint8_t *, uint8_t *,
+                                            unsigned long long *, uint8_t *, FxPayResult *, const FxTables *);
+
+namespace {
+
+thread_local std::string g_err;
+void set_err(const std::string &s) { g_err = s; }
+
+#define HIP_OK(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) {                                                               \
+            set_err(std::string(#expr) + ": " + hipGetErrorString(e_));                       \
+            return FXRX_ERR_HIP;                                                              \
+        }                                                                                     \
+    } while (0)
+
+// growable device / pinned-host buffers
+template <class T> struct DevBuf {
+    T *p = nullptr; size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        size_t nc = std::max(n, cap + cap / 2);
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        if (hipMalloc((void **)&p, nc * sizeof(T)) != hipSuccess) { set_err("hipMalloc failed"); return FXRX_ERR_HIP; }
+        cap = nc; return 0;
+    }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+template <class T> struct PinBuf {
+    T *p = nullptr; size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        size_t nc = std::max(n, cap + cap / 2);
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        if (hipHostMalloc((void **)&p, nc * sizeof(T), hipHostMallocDefault) != hipSuccess) { set_err("hipHostMalloc failed"); return FXRX_ERR_HIP; }
+        cap = nc; return 0;
+    }
+    ~PinBuf() { if (p) (void)hipHostFree(p); }
+};
+
+struct StreamState {
+    DevBuf<float2> carry[2]; int cur = 0;   // double-buffered tail of the previous call
+    size_t carry_len = 0;
+    int64_t base = 0;                       // absolute index of work-buffer sample 0
+    int64_t pos = 0, floor_ = 0; bool fresh = true;   // resume state, relative to the work buffer
+    DevBuf<float2> work;                    // [carry | new] when a tail exists or input is on the host
+};
+
+struct PlanKey { unsigned n, check, fec0, fec1; bool operator<(const PlanKey &o) const { return std::tie(n, check, fec0, fec1) < std::tie(o.n, o.check, o.fec0, o.fec1); } };
+struct PlanDev { fx::PacketPlan plan; uint32_t perm0_off, perm1_off; };
+
+}  // namespace
+
+struct fxrx_ctx_s {
+    fxrx_config cfg{};
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[6]{};
+    FxTables *d_tables = nullptr;
+    std::vector<StreamState> st;
+    // walker
+    std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
+    DevBuf<FxWalkJob> d_jobs; DevBuf<FxWalkResult> d_res; DevBuf<FxFrame> d_frames;
+    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames;
+    // payload
+    std::map<PlanKey, PlanDev> plans; std::vector<uint32_t> perm_host; DevBuf<uint32_t> d_perm; size_t perm_uploaded = 0;
+    std::vector<FxPayJob> pjobs; std::vector<uint32_t> blk_job, blk_c0;
+    DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0;
+    DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_out; DevBuf<unsigned long long> d_dw;
+    DevBuf<FxPayResult> d_pres; PinBuf<FxPayResult> h_pres; PinBuf<uint8_t> h_out; PinBuf<float2> h_framesyms;
+    uint64_t n_syms_last = 0;
+    // results
+    struct Out { fxrx_frame f; int pjob; };
+    std::vector<Out> out;
+    fxrx_timing timing{};
+};
+
+namespace {
+
+int upload_tables(fxrx_ctx_s *c)
+{
+    const fx::HostTables &H = fx::host_tables();
+    const fx::BlockCodes &B = fx::block_codes();
+    std::unique_ptr<FxTables> t(new FxTables);
+    std::memset(t.get(), 0, sizeof(FxTables));
+    for (int i = 0; i < 512; i++) { t->tw[i] = make_float2(H.tw[i].re, H.tw[i].im); t->S[i] = make_float2(H.S[i].re, H.S[i].im); }
+    for (int i = 0; i < 1024; i++) t->sc[i] = make_float2(H.sc[i].re, H.sc[i].im);
+    for (int i = 0; i < FX_S_LEN; i++) t->s[i] = make_float2(H.s[i].re, H.s[i].im);
+    for (int i = 0; i < FX_HDR_PILOTS; i++) t->pilots[i] = make_float2(H.pilots[i].re, H.pilots[i].im);
+    std::memcpy(t->proto, H.proto, sizeof H.proto);
+    t->s2sum = H.s2sum;
+    for (size_t i = 0; i < H.perm54.size(); i++) t->perm54[i] = (uint16_t)H.perm54[i];
+    for (size_t i = 0; i < H.perm27.size(); i++) t->perm27[i] = (uint16_t)H.perm27[i];
+    std::memcpy(t->h84dec, B.h84_dec, 256); std::memcpy(t->sdcol, B.sd_col, 64);
+    HIP_OK(hipMalloc((void **)&c->d_tables, sizeof(FxTables)));
+    HIP_OK(hipMemcpy(c->d_tables, t.get(), sizeof(FxTables), hipMemcpyHostToDevice));
+    return 0;
+}
+
+const PlanDev &get_plan(fxrx_ctx_s *c, unsigned n, unsigned check, unsigned fec0, unsigned fec1)
+{
+    PlanKey k{ n, check, fec0, fec1 };
+    auto it = c->plans.find(k);
+    if (it != c->plans.end()) return it->second;
+    PlanDev pd; pd.plan = fx::packet_plan(n, check, fec0, fec1);
+    std::vector<uint32_t> g0 = fx::Interleaver(pd.plan.l0).decode_gather(), g1 = fx::Interleaver(pd.plan.l1).decode_gather();
+    pd.perm0_off = (uint32_t)c->perm_host.size(); c->perm_host.insert(c->perm_host.end(), g0.begin(), g0.end());
+    pd.perm1_off = (uint32_t)c->perm_host.size(); c->perm_host.insert(c->perm_host.end(), g1.begin(), g1.end());
+    return c->plans.emplace(k, pd).first->second;
+}
+
+inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)(seg / 512 + 8); }
+
+int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
+{
+    HIP_OK(hipMemcpyAsync(c->d_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(fx_walk_kernel, dim3((unsigned)count), dim3(256), 0, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+}  // namespace
+
+// ============================================================================ batched API
+extern "C" {
+
+const char *fxrx_last_error(void) { return g_err.c_str(); }
+const char *fxrx_version(void) { return "fxrx 0.1 (gfx950)"; }
+int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+fxrx_ctx *fxrx_create(const fxrx_config *cfg)
+{
+    if (!cfg || cfg->n_streams == 0) { set_err("fxrx_create: bad config"); return nullptr; }
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || cfg->device >= nd) {
+        set_err("fxrx_create: no usable HIP device (this library has no CPU path)"); return nullptr;
+    }
+    if (hipSetDevice(cfg->device) != hipSuccess) { set_err("hipSetDevice failed"); return nullptr; }
+    std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
+    c->cfg = *cfg;
+    if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
+    if (upload_tables(c.get()) != 0) return nullptr;
+    c->st.resize(cfg->n_streams);
+    return c.release();
+}
+
+void fxrx_destroy(fxrx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->cfg.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+void fxrx_reset(fxrx_ctx *c)
+{
+    if (!c) return;
+    for (auto &s : c->st) { s.carry_len = 0; s.base = 0; s.pos = 0; s.floor_ = 0; s.fresh = true; }
+    c->out.clear();
+}
+
+void *fxrx_stream(const fxrx_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t) { if (!c || !t) return FXRX_ERR_ARG; *t = c->timing; return 0; }
+
+const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n) { if (!c) return nullptr; if (n) *n = c->n_syms_last; return c->n_syms_last ? c->d_framesyms.p : nullptr; }
+
+int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
+{
+    if (!c || !iq || !n_samples) { set_err("fxrx_process: null argument"); return FXRX_ERR_ARG; }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    const unsigned NS = c->cfg.n_streams;
+    const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
+    c->out.clear(); c->timing = fxrx_timing{};
+
+    // ---- 1. per-stream work buffers: [tail of previous call | new samples] ----
+    std::vector<const float2 *> xs(NS); std::vector<int64_t> ns(NS);
+    uint64_t total_new = 0;
+    for (unsigned s = 0; s < NS; s++) {
+        StreamState &S = c->st[s];
+        const uint64_t nn = n_samples[s];
+        total_new += nn;
+        if (S.carry_len == 0 && on_device) { xs[s] = (const float2 *)iq[s]; ns[s] = (int64_t)nn; continue; }
+        if (S.work.reserve(S.carry_len + nn + 1)) return FXRX_ERR_HIP;
+        if (S.carry_len) HIP_OK(hipMemcpyAsync(S.work.p, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+        if (nn) HIP_OK(hipMemcpyAsync(S.work.p + S.carry_len, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        xs[s] = S.work.p; ns[s] = (int64_t)(S.carry_len + nn);
+    }
+    c->timing.samples = total_new;
+
+    // ---- 2. walk jobs: cut every stream into segments ----
+    uint64_t seg = c->cfg.segment_len;
+    if (seg == 0) {
+        uint64_t tot = 0; for (unsigned s = 0; s < NS; s++) tot += (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
+        seg = tot / 1024;                                   // aim at ~4 workgroups per CU
+        seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
+    }
+    seg = std::max<uint64_t>(seg, 4096);
+    c->jobs.clear(); c->job_stream.clear();
+    std::vector<size_t> first_job(NS + 1);
+    uint32_t frame_slots = 0;
+    for (unsigned s = 0; s < NS; s++) {
+        StreamState &S = c->st[s];
+        first_job[s] = c->jobs.size();
+        int64_t p = S.pos;
+        bool first = true;
+        while (first || p < ns[s]) {
+            FxWalkJob j{};
+            j.x = xs[s]; j.n = ns[s]; j.start = p;
+            j.stop = std::min<int64_t>(ns[s], p + (int64_t)seg);
+            if (ns[s] - j.stop < (int64_t)seg / 2) j.stop = ns[s];          // fold a short last segment in
+            j.fresh = first ? (S.fresh ? 1u : 0u) : 1u;
+            j.floor = first ? S.floor_ : p;
+            j.mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
+            j.handoff = j.stop < ns[s] ? 1u : 0u;
+            j.prelock = first ? 0u : 1u;
+            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + seg);
+            frame_slots += j.max_frames;
+            j.threshold = c->cfg.threshold;
+            c->jobs.push_back(j); c->job_stream.push_back(s);
+            p = j.stop; first = false;
+            if (p >= ns[s]) break;
+        }
+    }
+    first_job[NS] = c->jobs.size();
+    const size_t NJ = c->jobs.size();
+    // one spare job slot + frame region for repairs
+    const uint32_t repair_base = frame_slots; const uint32_t repair_cap = seg_frames_cap(4 * seg);
+    frame_slots += repair_cap;
+    if (c->d_jobs.reserve(NJ + 1) || c->d_res.reserve(NJ + 1) || c->h_res.reserve(NJ + 1) ||
+        c->d_frames.reserve(frame_slots) || c->h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
+    c->jobs.resize(NJ + 1);
+
+    HIP_OK(hipEventRecord(c->ev[0], c->stream));
+    if (launch_walk(c, 0, NJ)) return FXRX_ERR_HIP;
+    HIP_OK(hipEventRecord(c->ev[1], c->stream));
+    HIP_OK(hipMemcpyAsync(c->h_res.p, c->d_res.p, NJ * sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipMemcpyAsync(c->h_frames.p, c->d_frames.p, (size_t)repair_base * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
+    HIP_OK(hipStreamSynchronize(c->stream));
+    c->timing.walk_jobs = NJ;
+
+    // ---- 3. stitch: per stream, splice speculative lists into the sequential chain ----
+    struct Chain { std::vector<FxFrame> frames; int64_t pos, floor_; bool fresh; };
+    std::vector<Chain> chains(NS);
+    for (unsigned s = 0; s < NS; s++) {
+        Chain &ch = chains[s];
+        size_t cur = first_job[s]; uint32_t m = 0;
+        FxWalkResult R = c->h_res.p[cur]; const FxFrame *F = c->h_frames.p + c->jobs[cur].frame_base;
+        std::vector<FxFrame> repair_frames; float splice_rxy = -1.0f;
+        for (;;) {
+            c->timing.hops += R.hops;
+            uint32_t nf = R.n_frames;
+            if (R.exit_code == FX_EXIT_PAYLOAD && nf > 0) nf--;            // incomplete frame: redo next call
+            for (uint32_t i = m; i < nf; i++) {
+                if (!(F[i].flags & FX_FLAG_EXACT)) continue;               // tentative pre-lock entries of a speculative walk
+                ch.frames.push_back(F[i]);
+                if (i == m && splice_rxy >= 0.0f) ch.frames.back().rxy = splice_rxy;   // coarse peak as the true chain saw it
+            }
+            splice_rxy = -1.0f;
+            const bool last = (cur + 1 == first_job[s + 1]);
+            if (R.exit_code == FX_EXIT_TABLE_FULL) {
+                // continue the same segment from where the table filled up
+                FxWalkJob j = c->jobs[cur]; j.start = R.pos; j.fresh = R.fresh; j.floor = R.floor; j.prelock = 0;
+                j.frame_base = repair_base; j.max_frames = repair_cap;
+                c->jobs[NJ] = j;
+                if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
+                HIP_OK(hipMemcpyAsync(c->h_res.p + NJ, c->d_res.p + NJ, sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(hipMemcpyAsync(c->h_frames.p + repair_base, c->d_frames.p + repair_base, (size_t)repair_cap * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
+                HIP_OK(hipStreamSynchronize(c->stream));
+                c->timing.repairs++;
+                R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
+                F = repair_frames.data(); m = 0;
+                continue;
+            }
+            if (last || R.exit_code != FX_EXIT_STOP || !R.has_handoff) { ch.pos = R.pos; ch.floor_ = R.floor; ch.fresh = R.fresh != 0; break; }
+            // hand-off: look the target up in the next segment's speculative list
+            // (segments the true walker crossed without a detection cannot hold the target: skip them)
+            size_t nxt = cur + 1;
+            while (nxt + 1 < first_job[s + 1] && R.handoff_start >= c->jobs[nxt].stop + FX_HOP) nxt++;
+            const FxWalkResult &RN = c->h_res.p[nxt]; const FxFrame *FN = c->h_frames.p + c->jobs[nxt].frame_base;
+            uint32_t found = UINT32_MAX;
+            for (uint32_t i = 0; i < RN.n_frames; i++)
+                if ((FN[i].flags & FX_FLAG_EXACT) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; break; }
+            if (found != UINT32_MAX) { splice_rxy = R.handoff_rxy; cur = nxt; m = found; R = RN; F = FN; continue; }
+            // repair: walk the next segment from the true state
+            FxWalkJob j = c->jobs[nxt]; j.start = R.pos; j.fresh = R.fresh; j.floor = R.floor; j.prelock = 0;
+            j.frame_base = repair_base; j.max_frames = repair_cap;
+            c->jobs[NJ] = j;
+            if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(c->h_res.p + NJ, c->d_res.p + NJ, sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipMemcpyAsync(c->h_frames.p + repair_base, c->d_frames.p + repair_base, (size_t)repair_cap * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            c->timing.repairs++;
+            R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
+            F = repair_frames.data(); m = 0; cur = nxt;
+        }
+    }
+
+    // ---- 4. payload jobs ----
+    c->pjobs.clear(); c->blk_job.clear(); c->blk_c0.clear();
+    uint64_t sym_total = 0, byte_total = 0, dw_total = 0, out_total = 0;
+    for (unsigned s = 0; s < NS; s++) {
+        for (const FxFrame &f : chains[s].frames) {
+            fxrx_ctx_s::Out o{}; std::memset(&o.f, 0, sizeof o.f);
+            o.f.stream = s; o.f.start = c->st[s].base + f.start; o.f.cfo_bin = f.offset;
+            o.f.rxy = f.rxy; o.f.tau = f.tau; o.f.gamma = f.gamma; o.f.dphi = f.dphi; o.f.phi = f.phi; o.f.pfb_index = f.pfb;
+            o.f.pilot_dphi = f.pilot_dphi; o.f.pilot_phi = f.pilot_phi; o.f.pilot_gain = f.pilot_gain;
+            o.f.header_valid = (f.flags & FX_FLAG_HEADER_VALID) ? 1 : 0;
+            std::memcpy(o.f.header, f.header, FX_HDR_DEC);
+            o.f.rssi_db = 20.0f * log10f(f.gamma); o.f.cfo = f.dphi;
+            o.pjob = -1;
+            if (!detect && o.f.header_valid) {
+                const PlanDev &pd = get_plan(c, f.pay_len, f.check, f.fec0, f.fec1);
+                FxPayJob j{};
+                j.x = xs[s]; j.start = f.start; j.mix_th = f.mix_th; j.mix_dl = f.mix_dl; j.mf_scale = f.mf_scale;
+                j.pfb = f.pfb; j.mfc0 = f.mfc0; j.pll_th = f.pll_th; j.pll_f = f.pll_f; j.ms = f.ms; j.bps = fx::modem_bps(f.ms);
+                j.nsym = f.pay_sym_len; j.sym_off = (uint32_t)sym_total;
+                j.pay_len = f.pay_len; j.check = f.check; j.fec0 = f.fec0; j.fec1 = f.fec1;
+                j.k = pd.plan.k; j.l0 = pd.plan.l0; j.l1 = pd.plan.l1; j.perm0_off = pd.perm0_off; j.perm1_off = pd.perm1_off;
+                j.byte_off = (uint32_t)byte_total; j.dw_off = (uint32_t)dw_total; j.out_off = (uint32_t)out_total;
+                o.pjob = (int)c->pjobs.size();
+                for (uint32_t c0 = 0; c0 < j.nsym; c0 += 1024) { c->blk_job.push_back((uint32_t)o.pjob); c->blk_c0.push_back(c0); }
+                sym_total += j.nsym;
+                byte_total += (uint64_t)((std::max(j.l1, j.k) + 8 + 15) & ~15u);
+                dw_total += 8ull * std::max(j.l0, j.k) + 6 + 64;
+                out_total += (j.pay_len + 15) & ~15u;
+                c->pjobs.push_back(j);
+                o.f.mod_scheme = f.ms; o.f.mod_bps = j.bps; o.f.check = f.check; o.f.fec0 = f.fec0; o.f.fec1 = f.fec1;
+                o.f.payload_len = f.pay_len; o.f.num_framesyms = f.pay_sym_len;
+            }
+            c->out.push_back(o);
+        }
+    }
+    c->timing.frames = c->out.size(); c->timing.payload_symbols = sym_total; c->n_syms_last = sym_total;
+    if (sym_total >= (1ull << 32) || byte_total >= (1ull << 32) || dw_total >= (1ull << 32)) { set_err("fxrx_process: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
+
+    const size_t NP = c->pjobs.size();
+    HIP_OK(hipEventRecord(c->ev[2], c->stream));
+    if (NP) {
+        if (c->perm_uploaded != c->perm_host.size()) {
+            if (c->d_perm.reserve(c->perm_host.size())) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(c->d_perm.p, c->perm_host.data(), c->perm_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            c->perm_uploaded = c->perm_host.size();
+        }
+        if (c->d_pjobs.reserve(NP) || c->d_blk_job.reserve(c->blk_job.size()) || c->d_blk_c0.reserve(c->blk_c0.size()) ||
+            c->d_symraw.reserve(sym_total) || c->d_framesyms.reserve(sym_total) || c->d_hard.reserve(sym_total + 16) ||
+            c->d_bufA.reserve(byte_total) || c->d_bufB.reserve(byte_total) || c->d_dw.reserve(dw_total) ||
+            c->d_out.reserve(out_total + 16) || c->d_pres.reserve(NP) || c->h_pres.reserve(NP) || c->h_out.reserve(out_total + 16)) return FXRX_ERR_HIP;
+        HIP_OK(hipMemcpyAsync(c->d_pjobs.p, c->pjobs.data(), NP * sizeof(FxPayJob), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->d_blk_job.p, c->blk_job.data(), c->blk_job.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(c->d_blk_c0.p, c->blk_c0.data(), c->blk_c0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(fx_paymf_kernel, dim3((unsigned)c->blk_job.size()), dim3(256), 0, c->stream,
+                           c->d_pjobs.p, c->d_blk_job.p, c->d_blk_c0.p, c->d_symraw.p, c->d_tables);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(c->ev[3], c->stream));
+        hipLaunchKernelGGL(fx_paypll_kernel, dim3((unsigned)((NP + 63) / 64)), dim3(64), 0, c->stream,
+                           c->d_pjobs.p, (uint32_t)NP, c->d_symraw.p, c->d_framesyms.p, c->d_hard.p, c->d_pres.p, c->d_tables);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(c->ev[4], c->stream));
+        hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, c->stream,
+                           c->d_pjobs.p, c->d_hard.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_dw.p, c->d_out.p, c->d_pres.p, c->d_tables);
+        HIP_OK(hipGetLastError());
+        HIP_OK(hipEventRecord(c->ev[5], c->stream));
+        HIP_OK(hipMemcpyAsync(c->h_pres.p, c->d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipMemcpyAsync(c->h_out.p, c->d_out.p, out_total, hipMemcpyDeviceToHost, c->stream));
+        if (c->cfg.want_framesyms) {
+            if (c->h_framesyms.reserve(sym_total)) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(c->h_framesyms.p, c->d_framesyms.p, sym_total * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+        }
+    } else {
+        for (int i = 3; i <= 5; i++) HIP_OK(hipEventRecord(c->ev[i], c->stream));
+    }
+
+    // ---- 5. carry the unconsumed tail of every stream into the next call ----
+    for (unsigned s = 0; s < NS; s++) {
+        StreamState &S = c->st[s]; const Chain &ch = chains[s];
+        int64_t keep_from = ch.fresh ? ch.pos : ch.pos - FX_HOP;
+        keep_from = std::max<int64_t>(0, std::min<int64_t>(keep_from, ns[s]));
+        const size_t keep = (size_t)(ns[s] - keep_from);
+        const int nxt = S.cur ^ 1;
+        if (keep) {
+            if (S.carry[nxt].reserve(keep)) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(S.carry[nxt].p, xs[s] + keep_from, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+        }
+        S.cur = nxt; S.carry_len = keep; S.base += keep_from;
+        S.pos = ch.pos - keep_from; S.floor_ = ch.floor_ - keep_from; S.fresh = ch.fresh;
+    }
+    HIP_OK(hipStreamSynchronize(c->stream));
+
+    for (auto &o : c->out) {
+        if (o.pjob < 0) continue;
+        const FxPayJob &j = c->pjobs[(size_t)o.pjob]; const FxPayResult &r = c->h_pres.p[o.pjob];
+        o.f.payload = c->h_out.p + j.out_off; o.f.payload_valid = (int)r.payload_valid;
+        o.f.evm_sum = r.evm_sum; o.f.evm_db = 10.0f * log10f(r.evm_sum / (float)(j.nsym ? j.nsym : 1));
+        o.f.framesyms = c->cfg.want_framesyms ? (const fx_complex *)(c->h_framesyms.p + j.sym_off) : nullptr;
+    }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->timing.walk_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->timing.paymf_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->timing.paypll_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->timing.paydec_ms = ms;
+    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); c->timing.total_ms = ms;
+    return (int)c->out.size();
+}
+
+int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out)
+{
+    if (!c || !out || i >= c->out.size()) return FXRX_ERR_ARG;
+    *out = c->out[i].f; return 0;
+}
+
+unsigned int fxrx_gen_frame_len(unsigned int ms, unsigned int check, unsigned int fec0, unsigned int fec1, unsigned int n)
+{
+    fx::FrameGen g; g.ms = ms; g.check = check; g.fec0 = fec0; g.fec1 = fec1;
+    return g.frame_len(n);
+}
+
+// ---- block-API index maps (reference: lib/flex_tx_impl.cc:75-181, lib/flex_rx_impl.cc:74-179) ----
+static const int kMod[11] = { FX_MODEM_PSK2, FX_MODEM_PSK4, FX_MODEM_PSK8, FX_MODEM_PSK16, FX_MODEM_DPSK2, FX_MODEM_DPSK4,
+                              FX_MODEM_DPSK8, FX_MODEM_ASK4, FX_MODEM_QAM16, FX_MODEM_QAM32, FX_MODEM_QAM64 };
+static const int kInner[7] = { FX_FEC_NONE, FX_FEC_CONV_V27, FX_FEC_CONV_V27P23, FX_FEC_CONV_V27P45, FX_FEC_CONV_V27P56,
+                               FX_FEC_CONV_V27P67, FX_FEC_CONV_V27P78 };
+static const int kOuter[8] = { FX_FEC_NONE, FX_FEC_GOLAY2412, FX_FEC_RS_M8, FX_FEC_HAMMING74, FX_FEC_HAMMING128,
+                               FX_FEC_SECDED2216, FX_FEC_SECDED3932, FX_FEC_SECDED7264 };
+int fxrx_mod_from_index(int i) { return (i >= 0 && i < 11) ? kMod[i] : -1; }
+int fxrx_inner_from_index(int i) { return (i >= 0 && i < 7) ? kInner[i] : -1; }
+int fxrx_outer_from_index(int i) { return (i >= 0 && i < 8) ? kOuter[i] : -1; }
+int fxrx_mod_to_index(unsigned v) { for (int i = 0; i < 11; i++) if ((unsigned)kMod[i] == v) return i; return -1; }
+int fxrx_inner_to_index(unsigned v) { for (int i = 0; i < 7; i++) if ((unsigned)kInner[i] == v) return i; return -1; }
+int fxrx_outer_to_index(unsigned v) { for (int i = 0; i < 8; i++) if ((unsigned)kOuter[i] == v) return i; return -1; }
+
+}  // extern "C"

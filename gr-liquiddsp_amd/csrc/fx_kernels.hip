@@ -1,0 +1,705 @@
+// fx_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the flexframe receive path.
+//
+// What liquid-dsp does one sample at a time inside flexframesync_execute / qdetector_cccf_execute
+// (call sites /root/reference/lib/flex_rx_impl.cc:213 and /root/reference/lib/frame_detector_cc_impl.cc:77)
+// is regrouped here into four kernels:
+//
+//   fx_walk_kernel      one workgroup walks one stream segment through the synchroniser's state
+//                       machine: hop-wise FFT cross-correlation with the +-24-bin CFO sweep
+//                       (qdetector SEEK), ALIGN estimates (tau, gamma, dphi, phi), then -- flex_rx mode --
+//                       NCO mix + polyphase MF of the preamble/header span, pilot sync, header decode.
+//                       Emits one FxFrame per detection and the position where the detector restarts.
+//   fx_paymf_kernel     per frame, data parallel: closed-form NCO mix (32-bit phase) + fixed-branch
+//                       polyphase matched filter + decimate-by-2 over the payload span.
+//   fx_paypll_kernel    one lane per frame: the decision-directed payload PLL (the only true
+//                       sample-to-sample recurrence of the path), hard demod, EVM.
+//   fx_paydec_kernel    one wavefront per frame: bit de-interleave, K=7 Viterbi (lane = state),
+//                       block codes, de-whitening, CRC.
+//
+// No MFMA anywhere: nothing on this path is a dense contraction.  Taps, windows, spectra and the
+// FFT exchange buffers live in LDS; IQ is read from HBM as coalesced float2.
+#include <hip/hip_runtime.h>
+#include "fx_device.h"
+
+#define WALK_THREADS 256
+#define WALK_WAVES   4
+
+struct WalkLds {
+    float2 win[FX_NFFT];            // time window of the current hop / aligned window
+    float2 X[FX_NFFT];              // its spectrum
+    float2 S[FX_NFFT];              // template spectrum
+    float2 scr[WALK_WAVES][576];    // per-wave FFT exchange buffers
+    float2 v[640];                  // mixed-down samples of the preamble+header span
+    float2 P[256];                  // x conj(s) products (ALIGN)
+    float  m2[FX_NFFT];
+    float2 hdr[FX_HDR_SYM];
+    float2 pb[16];                  // de-rotated pilots
+    float  taps[FX_MF_TAPS];
+    float  redf[WALK_WAVES]; float2 redc[WALK_WAVES];
+    float  redv[WALK_WAVES]; uint32_t redk[WALK_WAVES];
+    float  f[16];                   // scalar broadcast slots
+    uint32_t u[16];
+    uint8_t hs[FX_HDR_MOD];
+    uint8_t b0[64], b1[64];
+};
+
+// ---- workgroup reductions (all 256 threads call; result on every thread) ----
+__device__ __forceinline__ float block_sum256(float v, WalkLds &L, int lane, int wave)
+{
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) L.redf[wave] = v;
+    __syncthreads();
+    return (L.redf[0] + L.redf[1]) + (L.redf[2] + L.redf[3]);
+}
+__device__ __forceinline__ float2 block_csum256(float2 v, WalkLds &L, int lane, int wave)
+{
+    v.x = wave_sum(v.x); v.y = wave_sum(v.y);
+    __syncthreads();
+    if (lane == 0) L.redc[wave] = v;
+    __syncthreads();
+    float2 a = cadd(L.redc[0], L.redc[1]), b = cadd(L.redc[2], L.redc[3]);
+    return cadd(a, b);
+}
+
+// samples below `floor` (before the last synchroniser reset) and outside the stream read as zero
+__device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_, int64_t n)
+{
+    return (p >= floor_ && p < n) ? x[p] : make_float2(0.0f, 0.0f);
+}
+
+// header: 54 received bytes -> 20 header bytes + CRC verdict.  Single thread, ~2k integer ops.
+__device__ int decode_header_bytes(WalkLds &L, const FxTables *T, uint8_t *out)
+{
+    uint8_t *b0 = L.b0, *b1 = L.b1;
+    for (int j = 0; j < FX_HDR_ENC; j++) b1[j] = 0;
+    for (int i = 0; i < FX_HDR_ENC * 8; i++) {           // de-interleave (54)
+        unsigned s = T->perm54[i];
+        if ((b0[s >> 3] >> (7 - (s & 7))) & 1) b1[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
+    }
+    for (int j = 0; j < FX_HDR_E0; j++)                  // Hamming(8,4)
+        b0[j] = (uint8_t)((T->h84dec[b1[2 * j]] << 4) | T->h84dec[b1[2 * j + 1]]);
+    for (int j = 0; j < FX_HDR_E0; j++) b1[j] = 0;
+    for (int i = 0; i < FX_HDR_E0 * 8; i++) {            // de-interleave (27)
+        unsigned s = T->perm27[i];
+        if ((b0[s >> 3] >> (7 - (s & 7))) & 1) b1[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
+    }
+    for (int blk = 0; blk < 3; blk++) {                  // SECDED(72,64)
+        const uint8_t *e = b1 + 9 * blk; uint8_t *d = b0 + 8 * blk;
+        uint8_t par = 0;
+        for (int j = 0; j < 8; j++) d[j] = e[1 + j];
+        for (int j = 0; j < 64; j++) if (d[j >> 3] & (0x80u >> (j & 7))) par ^= T->sdcol[j];
+        uint8_t syn = (uint8_t)(e[0] ^ par);
+        if (syn != 0 && __popc((unsigned)syn) != 1)
+            for (int j = 0; j < 64; j++) if (T->sdcol[j] == syn) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); break; }
+    }
+    const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
+    for (int j = 0; j < FX_HDR_CRC; j++) b0[j] ^= mask[j & 3];
+    uint32_t key = 0xFFFFFFFFu;
+    for (int j = 0; j < FX_HDR_DEC; j++) {
+        key ^= b0[j];
+        for (int b = 0; b < 8; b++) key = (key >> 1) ^ (0xEDB88320u & (0u - (key & 1u)));
+    }
+    key = ~key;
+    uint32_t rx = ((uint32_t)b0[20] << 24) | ((uint32_t)b0[21] << 16) | ((uint32_t)b0[22] << 8) | b0[23];
+    for (int j = 0; j < FX_HDR_DEC; j++) out[j] = b0[j];
+    return key == rx;
+}
+
+extern "C" __global__ __launch_bounds__(WALK_THREADS)
+void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, const FxTables *T)
+{
+    __shared__ WalkLds L;
+    const FxWalkJob job = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float2 *x = job.x;
+    const int64_t n = job.n;
+
+    float2 twA[7], twB[7];
+#pragma unroll
+    for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
+    L.S[tid] = T->S[tid]; L.S[tid + 256] = T->S[tid + 256];
+
+    int64_t pos = job.start, floor_ = job.floor;
+    bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
+    uint32_t nfr = 0, hops = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
+    int64_t ho_start = 0; int32_t ho_off = 0; float ho_rxy = 0.0f;
+    float x2_0 = 0.0f;
+    const float s2sum = T->s2sum;
+    const float2 *sc = T->sc;
+
+    if (fresh) L.win[tid] = make_float2(0.0f, 0.0f);
+    else { float2 w = xv(x, pos - FX_HOP + tid, floor_, n); L.win[tid] = w; x2_0 = block_sum256(cm2(w), L, lane, wave); }
+    __syncthreads();
+
+    for (;;) {
+        if (pos >= job.stop && !in_handoff) {
+            if (job.handoff) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }
+        }
+        if (pos + FX_HOP > n) { exit_code = FX_EXIT_NEED_DATA; break; }
+
+        // ------------------------------------------------------------ SEEK: one 256-sample hop
+        float2 nw = xv(x, pos + tid, floor_, n);
+        L.win[FX_HOP + tid] = nw;
+        const float x2_1 = block_sum256(cm2(nw), L, lane, wave);     // barriers inside publish win[]
+        hops++;
+        const float g0 = sqrtf(x2_0 + x2_1) * sqrtf((float)FX_S_LEN / (float)FX_NFFT);
+        bool det = false; uint32_t bidx = 0; int boff = 0; float peak = 0.0f;
+        if (!(g0 < 1e-10f)) {
+            float2 a[8];
+            if (wave == 0) {                                          // forward FFT of the window
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = L.win[lane + 64 * q];
+                fft512_wave(a, L.scr[0], lane, twA, twB);
+                const int kb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+                for (int t = 0; t < 8; t++) L.X[kb + 64 * t] = a[t];
+            }
+            __syncthreads();
+            // CFO sweep: offsets -24..24 dealt round-robin to the 4 waves
+            float bv = -1.0f; uint32_t bk = 0xFFFFFFFFu;
+            for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += WALK_WAVES) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * q;
+                    float2 y = cmulc(L.X[i], L.S[(i - off) & (FX_NFFT - 1)]);
+                    a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
+                }
+                fft512_wave(a, L.scr[wave], lane, twA, twB);
+                const uint32_t kb = (uint32_t)(off + FX_RANGE) * FX_NFFT + (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    float m = fmaf(a[t].y, a[t].y, a[t].x * a[t].x);  // |R|^2, R = (a.y, a.x)
+                    uint32_t k = kb + 64 * t;
+                    bool take = (m > bv) || (m == bv && k < bk);
+                    bv = take ? m : bv; bk = take ? k : bk;
+                }
+            }
+            wave_argmax(bv, bk);
+            if (lane == 0) { L.redv[wave] = bv; L.redk[wave] = bk; }
+            __syncthreads();
+            bv = L.redv[0]; bk = L.redk[0];
+#pragma unroll
+            for (int w = 1; w < WALK_WAVES; w++) {
+                float ov = L.redv[w]; uint32_t ok = L.redk[w];
+                bool take = (ov > bv) || (ov == bv && ok < bk);
+                bv = take ? ov : bv; bk = take ? ok : bk;
+            }
+            const float g = 1.0f / ((float)FX_NFFT * g0 * sqrtf(s2sum));
+            peak = sqrtf(bv) * g;
+            bidx = bk & (FX_NFFT - 1); boff = (int)(bk >> 9) - FX_RANGE;
+            det = (peak > job.threshold) && (bidx < FX_NFFT - FX_S_LEN);
+        }
+        if (!det) {                                                    // slide the window by one hop
+            __syncthreads();
+            L.win[tid] = nw;
+            x2_0 = x2_1; pos += FX_HOP; fresh = false;
+            __syncthreads();
+            continue;
+        }
+
+        const int64_t a0 = pos - FX_HOP + (int64_t)bidx;
+        if (in_handoff) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; exit_code = FX_EXIT_STOP; break; }
+        if (nfr >= job.max_frames) { exit_code = FX_EXIT_TABLE_FULL; break; }
+        if (a0 + FX_NFFT > n) { exit_code = FX_EXIT_NEED_DATA; break; }
+
+        // ------------------------------------------------------------ ALIGN on x[a0, a0+512)
+        __syncthreads();
+        L.win[tid] = xv(x, a0 + tid, floor_, n);
+        L.win[tid + 256] = xv(x, a0 + 256 + tid, floor_, n);
+        __syncthreads();
+        if (wave == 0) {
+            float2 a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = L.win[lane + 64 * q];
+            fft512_wave(a, L.scr[0], lane, twA, twB);
+            const int kb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+            for (int t = 0; t < 8; t++) L.X[kb + 64 * t] = a[t];
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = lane + 64 * q;
+                float2 y = cmulc(L.X[i], L.S[(i - boff) & (FX_NFFT - 1)]);
+                a[q] = make_float2(y.y, y.x);
+            }
+            fft512_wave(a, L.scr[0], lane, twA, twB);
+            // lags 0, +1, -1 sit in lanes 0 (t=0), 8 (t=0), 63 (t=7)
+            if (lane == 0)  L.f[0] = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);
+            if (lane == 8)  L.f[1] = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);
+            if (lane == 63) L.f[2] = fmaf(a[7].y, a[7].y, a[7].x * a[7].x);
+        }
+        __syncthreads();
+        float tau, gamma;
+        {
+            float y0 = sqrtf(sqrtf(L.f[0])), ypos = sqrtf(sqrtf(L.f[1])), yneg = sqrtf(sqrtf(L.f[2]));
+            float qa = 0.5f * (ypos + yneg) - y0, qb = 0.5f * (ypos - yneg);
+            tau = qa == 0.0f ? 0.0f : -qb / (2.0f * qa);
+            if (!(fabsf(tau) < 1.0f)) tau = 0.0f;
+            float gh = fmaf(fmaf(qa, tau, qb), tau, y0);
+            gamma = gh * gh / ((float)FX_NFFT * s2sum);
+        }
+        // carrier frequency: spectral peak of x conj(s)
+        {
+            float2 p = make_float2(0.0f, 0.0f);
+            if (tid < FX_S_LEN) p = cmulc(L.win[tid], T->s[tid]);
+            L.P[tid] = p;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float2 a[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) a[q] = (q < 4) ? L.P[lane + 64 * q] : make_float2(0.0f, 0.0f);
+            fft512_wave(a, L.scr[0], lane, twA, twB);
+            const uint32_t kb = (lane >> 3) + 8 * (lane & 7);
+            float bv = -1.0f; uint32_t bk = 0;
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                float m = cm2(a[t]);
+                L.m2[kb + 64 * t] = m;
+                if (m > bv) { bv = m; bk = kb + 64 * t; }
+            }
+            wave_argmax(bv, bk);
+            if (lane == 0) { L.f[3] = bv; L.u[0] = bk; }
+        }
+        __syncthreads();
+        float dphi;
+        {
+            const uint32_t i0 = L.u[0];
+            float v0 = sqrtf(L.f[3]);
+            float vneg = sqrtf(L.m2[(i0 + FX_NFFT - 1) & (FX_NFFT - 1)]);
+            float vpos = sqrtf(L.m2[(i0 + 1) & (FX_NFFT - 1)]);
+            float qa = 0.5f * (vpos + vneg) - v0, qb = 0.5f * (vpos - vneg);
+            float idx = qa == 0.0f ? 0.0f : -qb / (2.0f * qa);
+            float index = (float)i0 + idx;
+            dphi = (i0 > FX_NFFT / 2 ? index - (float)FX_NFFT : index) * (6.28318531f / (float)FX_NFFT);
+        }
+        const uint32_t mix_dl = rad2u32(dphi);
+        float phi;
+        {
+            float2 term = make_float2(0.0f, 0.0f);
+            if (tid < FX_S_LEN) term = derot(L.P[tid], mix_dl * (uint32_t)tid, sc);
+            float2 metric = block_csum256(term, L, lane, wave);
+            phi = atan2c(metric.y, metric.x);
+        }
+
+        FxFrame fr;
+        fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
+        fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
+        fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f; fr.flags = 0;
+        fr.pay_len = fr.ms = fr.check = fr.fec0 = fr.fec1 = fr.pay_sym_len = 0;
+#pragma unroll
+        for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = 0;
+
+        if (job.mode == FX_MODE_DETECT) {
+            // Speculative walker not yet locked: a weak peak may be a false alarm the sequential chain
+            // never sees (its hop grid differs).  Ignore it and keep the grid; lock on a strong one.
+            if (!locked && !(peak > 0.7f)) {
+                __syncthreads();
+                L.win[tid] = nw; L.win[FX_HOP + tid] = make_float2(0.0f, 0.0f);
+                x2_0 = x2_1; pos += FX_HOP; fresh = false;
+                __syncthreads();
+                continue;
+            }
+            locked = true; fr.flags |= FX_FLAG_EXACT;
+            // back to SEEK with the second half of the aligned window as overlap
+            fr.next = a0 + FX_NFFT;
+            if (tid == 0) frames[job.frame_base + nfr] = fr;
+            nfr++;
+            __syncthreads();
+            float2 w = L.win[FX_HOP + tid];
+            __syncthreads();
+            L.win[tid] = w;
+            x2_0 = block_sum256(cm2(w), L, lane, wave);
+            pos = a0 + FX_NFFT; fresh = false;
+            __syncthreads();
+            continue;
+        }
+
+        // ------------------------------------------------------------ flex_rx: preamble + header span
+        if (tau > 0.0f) { fr.pfb = (unsigned)(tau * (float)FX_NPFB) % FX_NPFB; fr.mfc0 = 0; }
+        else { fr.pfb = (unsigned)((1.0f + tau) * (float)FX_NPFB) % FX_NPFB; fr.mfc0 = 1; }
+        fr.mf_scale = 0.5f / gamma;
+        const int nh = (int)sym_sample(FX_SYM0_PAY - 1, fr.mfc0);      // sample of the last header symbol
+        if (a0 + nh + 1 > n) { exit_code = FX_EXIT_NEED_DATA; break; }
+        for (int m = tid; m <= nh; m += WALK_THREADS)
+            L.v[m] = derot(xv(x, a0 + m, floor_, n), fr.mix_th + mix_dl * (uint32_t)m, sc);
+        if (tid < FX_MF_TAPS) L.taps[tid] = T->proto[fr.pfb + FX_NPFB * tid];
+        __syncthreads();
+        if (tid < FX_HDR_SYM) {
+            const int nc = (int)sym_sample(FX_SYM0_HDR + tid, fr.mfc0);
+            float ar = 0.0f, ai = 0.0f;
+#pragma unroll 4
+            for (int t = 0; t < FX_MF_TAPS; t++) {
+                const float2 w = L.v[nc - t]; const float h = L.taps[t];
+                ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+            }
+            L.hdr[tid] = make_float2(ar * fr.mf_scale, ai * fr.mf_scale);
+        }
+        __syncthreads();
+        // pilot sync: 32-point DFT of the 15 de-rotated pilots
+        if (tid < FX_HDR_PILOTS) L.pb[tid] = cmulc(L.hdr[FX_PILOT_SPACING * tid], T->pilots[tid]);
+        __syncthreads();
+        if (tid < 32) {
+            float ar = 0.0f, ai = 0.0f;
+            for (int p = 0; p < FX_HDR_PILOTS; p++) {
+                const float2 w = T->tw[16 * ((tid * p) & 31)], b = L.pb[p];
+                ar = fmaf(b.x, w.x, ar); ar = fmaf(-b.y, w.y, ar);
+                ai = fmaf(b.x, w.y, ai); ai = fmaf(b.y, w.x, ai);
+            }
+            L.m2[tid] = fmaf(ar, ar, ai * ai);
+        }
+        __syncthreads();
+        float pdphi, pphi, pgain;
+        {
+            float best = -1.0f; unsigned i0 = 0;
+            for (unsigned k = 0; k < 32; k++) { float m = L.m2[k]; if (m > best) { best = m; i0 = k; } }
+            float y0 = sqrtf(L.m2[i0]), yneg = sqrtf(L.m2[(i0 + 31) & 31]), ypos = sqrtf(L.m2[(i0 + 1) & 31]);
+            float qa = 0.5f * (ypos + yneg) - y0, qb = 0.5f * (ypos - yneg);
+            float idx = qa == 0.0f ? 0.0f : -qb / (2.0f * qa);
+            float index = i0 < 16 ? (float)i0 : (float)i0 - 32.0f;
+            pdphi = (index + idx) * (6.28318531f / 512.0f);
+        }
+        const uint32_t pdl = rad2u32(pdphi);
+        {
+            float mr = 0.0f, mi = 0.0f;
+            for (unsigned p = 0; p < FX_HDR_PILOTS; p++) {
+                float2 t = derot(L.pb[p], pdl * (FX_PILOT_SPACING * p), sc);
+                mr += t.x; mi += t.y;
+            }
+            pphi = atan2c(mi, mr);
+            pgain = sqrtf(fmaf(mr, mr, mi * mi)) / (float)FX_HDR_PILOTS;
+        }
+        const uint32_t pph = rad2u32(pphi);
+        const float pg = 1.0f / pgain;
+        if (tid < FX_HDR_SYM && (tid % FX_PILOT_SPACING) != 0) {
+            float2 y = derot(L.hdr[tid], pph + pdl * (uint32_t)tid, sc);
+            y.x *= pg; y.y *= pg;
+            const int nn = tid - 1 - tid / FX_PILOT_SPACING;           // data index (pilots removed)
+            L.hs[nn] = (uint8_t)((y.x > 0.0f ? 0u : 1u) | (y.y > 0.0f ? 0u : 2u));
+        }
+        __syncthreads();
+        if (tid < FX_HDR_ENC)
+            L.b0[tid] = (uint8_t)((L.hs[4 * tid] << 6) | (L.hs[4 * tid + 1] << 4) | (L.hs[4 * tid + 2] << 2) | L.hs[4 * tid + 3]);
+        __syncthreads();
+        if (tid == 0) {
+            uint8_t hd[FX_HDR_DEC];
+            int ok = decode_header_bytes(L, T, hd);
+            unsigned pay_len = 0, ms = 0, check = 0, fec0 = 0, fec1 = 0, nsym = 0;
+            if (ok) {
+                const uint8_t *h = hd + FX_HDR_USER;
+                pay_len = ((unsigned)h[1] << 8) | h[2]; ms = h[3];
+                check = (h[4] >> 5) & 7; fec0 = h[4] & 0x1f; fec1 = h[5] & 0x1f;
+                const unsigned bps = modem_bps(ms);
+                if (h[0] != FX_PROTOCOL || bps == 0 || check == FX_CRC_UNKNOWN || check > FX_CRC_32 ||
+                    !fec_supported(fec0) || !fec_supported(fec1)) ok = 0;
+                else {
+                    unsigned bits = 8 * fec_enc_len(fec1, fec_enc_len(fec0, pay_len + crc_len(check)));
+                    nsym = (bits + bps - 1) / bps;
+                }
+            }
+            for (int j = 0; j < FX_HDR_DEC; j++) L.b1[j] = hd[j];
+            L.u[1] = (uint32_t)ok; L.u[2] = pay_len; L.u[3] = ms; L.u[4] = check; L.u[5] = fec0; L.u[6] = fec1; L.u[7] = nsym;
+        }
+        __syncthreads();
+        const bool hv = L.u[1] != 0;
+        fr.pilot_dphi = pdphi; fr.pilot_phi = pphi; fr.pilot_gain = pgain;
+        fr.pll_f = pdphi; fr.pll_th = pph + pdl * (uint32_t)FX_HDR_SYM;
+#pragma unroll
+        for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = L.b1[j];
+        int64_t last_c = FX_SYM0_PAY - 1;
+        if (hv) {
+            fr.flags |= FX_FLAG_HEADER_VALID;
+            fr.pay_len = L.u[2]; fr.ms = L.u[3]; fr.check = L.u[4]; fr.fec0 = L.u[5]; fr.fec1 = L.u[6]; fr.pay_sym_len = L.u[7];
+            last_c += fr.pay_sym_len;
+        }
+        fr.next = a0 + sym_sample(last_c, fr.mfc0) + 1;
+        if (!locked && !hv) {
+            // speculative walker, header did not check out: most likely a false alarm on payload data.
+            // Do not skip the 618 samples a real invalid frame would consume (a true preamble may sit
+            // there); resume seeking on the same grid.  Nothing before the lock is ever spliced.
+            if (tid == 0) frames[job.frame_base + nfr] = fr;
+            nfr++;
+            __syncthreads();
+            L.win[tid] = xv(x, pos + tid, floor_, n);
+            x2_0 = x2_1; pos += FX_HOP; fresh = false;
+            __syncthreads();
+            continue;
+        }
+        locked = true; fr.flags |= FX_FLAG_EXACT;
+        bool incomplete = fr.next > n;
+        if (incomplete) fr.flags |= FX_FLAG_INCOMPLETE;
+        if (tid == 0) frames[job.frame_base + nfr] = fr;
+        nfr++;
+        if (incomplete) { exit_code = FX_EXIT_PAYLOAD; break; }
+        // synchroniser reset: fresh detector right after the frame's last symbol
+        pos = fr.next; floor_ = fr.next; fresh = true; x2_0 = 0.0f;
+        __syncthreads();
+        L.win[tid] = make_float2(0.0f, 0.0f);
+        __syncthreads();
+    }
+
+    if (tid == 0) {
+        FxWalkResult r;
+        r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
+        r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
+        r.handoff_rxy = ho_rxy; r.pad_ = 0;
+        results[blockIdx.x] = r;
+    }
+}
+
+// ===================================================================== payload: mix + polyphase MF
+#define PMF_THREADS 256
+#define PMF_SYMS    1024          // symbols per workgroup
+#define PMF_SPAN    (2 * PMF_SYMS + FX_MF_TAPS)
+
+extern "C" __global__ __launch_bounds__(PMF_THREADS)
+void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, float2 *sym_raw, const FxTables *T)
+{
+    __shared__ float2 v[PMF_SPAN + 4];
+    __shared__ float taps[FX_MF_TAPS];
+    const FxPayJob job = jobs[blk_job[blockIdx.x]];
+    const uint32_t c0 = blk_c0[blockIdx.x];                    // first payload symbol of this block
+    const uint32_t ns = min((uint32_t)PMF_SYMS, job.nsym - c0);
+    const int tid = threadIdx.x;
+    const int64_t nlo = sym_sample((int64_t)FX_SYM0_PAY + c0, job.mfc0) - (FX_MF_TAPS - 1);
+    const int64_t nhi = sym_sample((int64_t)FX_SYM0_PAY + c0 + ns - 1, job.mfc0);
+    const int span = (int)(nhi - nlo + 1);
+    const float2 *x = job.x + job.start;
+    const float2 *sc = T->sc;
+    if (tid < FX_MF_TAPS) taps[tid] = T->proto[job.pfb + FX_NPFB * tid];
+    for (int m = tid; m < span; m += PMF_THREADS) {
+        const int64_t nn = nlo + m;
+        v[m] = derot(x[nn], job.mix_th + job.mix_dl * (uint32_t)nn, sc);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
+        const int nc = (int)(sym_sample((int64_t)FX_SYM0_PAY + c0 + i, job.mfc0) - nlo);
+        float ar = 0.0f, ai = 0.0f;
+#pragma unroll 7
+        for (int t = 0; t < FX_MF_TAPS; t++) {
+            const float2 w = v[nc - t]; const float h = taps[t];
+            ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+        }
+        sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
+    }
+}
+
+// ===================================================================== payload: PLL + hard demod (lane per frame)
+#define PLL_THREADS 64
+
+extern "C" __global__ __launch_bounds__(PLL_THREADS)
+void fx_paypll_kernel(const FxPayJob *jobs, uint32_t njobs, const float2 *sym_raw, float2 *framesyms, uint8_t *hard,
+                      FxPayResult *res, const FxTables *T)
+{
+    __shared__ float2 sc[1024];
+    for (int i = threadIdx.x; i < 1024; i += PLL_THREADS) sc[i] = T->sc[i];
+    __syncthreads();
+    const uint32_t f = blockIdx.x * PLL_THREADS + threadIdx.x;
+    if (f >= njobs) return;
+    const FxPayJob job = jobs[f];
+    const float2 *in = sym_raw + job.sym_off;
+    float2 *out = framesyms + job.sym_off;
+    uint8_t *hd = hard + job.sym_off;
+    uint32_t th = job.pll_th; float fq = job.pll_f, evm = 0.0f; unsigned prev = 0;
+    const unsigned ms = job.ms, bps = job.bps;
+    for (uint32_t c = 0; c < job.nsym; c++) {
+        float2 r = derot(in[c], th, sc), xh; float pe;
+        unsigned s = modem_demod(ms, bps, r, prev, sc, xh, pe);
+        float dr = r.x - xh.x, di = r.y - xh.y;
+        evm += fmaf(dr, dr, di * di);
+        fq += pe * 1e-4f;
+        th += rad2u32(pe * 0.01f);
+        th += rad2u32(fq);
+        out[c] = r; hd[c] = (uint8_t)s;
+    }
+    res[f].evm_sum = evm;
+}
+
+// ===================================================================== payload: packet decode (wave per frame)
+#define DEC_THREADS 64
+
+__device__ __forceinline__ unsigned getbit(const uint8_t *b, uint32_t i) { return (b[i >> 3] >> (7 - (i & 7))) & 1u; }
+
+// gather-permute `nbytes` bytes bit by bit: dst bit i = src bit perm[i]
+__device__ void permute_bits(const uint8_t *src, uint8_t *dst, const uint32_t *perm, uint32_t nbytes, int lane)
+{
+    for (uint32_t j = lane; j < nbytes; j += DEC_THREADS) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v = (v << 1) | getbit(src, perm[8 * j + b]);
+        dst[j] = (uint8_t)v;
+    }
+}
+
+__device__ void block_fec_decode(unsigned fs, uint32_t n, const uint8_t *enc, uint8_t *dec, const FxTables *T, int lane)
+{
+    if (fs == FX_FEC_HAMMING84) {
+        for (uint32_t j = lane; j < n; j += DEC_THREADS)
+            dec[j] = (uint8_t)((T->h84dec[enc[2 * j]] << 4) | T->h84dec[enc[2 * j + 1]]);
+    } else if (fs == FX_FEC_SECDED7264) {
+        const uint32_t nblk = (n + 7) / 8;
+        for (uint32_t blk = lane; blk < nblk; blk += DEC_THREADS) {
+            const uint32_t nb = min(8u, n - 8 * blk);
+            uint8_t d[8]; uint8_t par = 0;
+            for (uint32_t j = 0; j < 8; j++) d[j] = j < nb ? enc[9 * blk + 1 + j] : 0;
+            for (int j = 0; j < 64; j++) if (d[j >> 3] & (0x80u >> (j & 7))) par ^= T->sdcol[j];
+            uint8_t syn = (uint8_t)(enc[9 * blk] ^ par);
+            if (syn != 0 && __popc((unsigned)syn) != 1)
+                for (int j = 0; j < 64; j++) if (T->sdcol[j] == syn) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); break; }
+            for (uint32_t j = 0; j < nb; j++) dec[8 * blk + j] = d[j];
+        }
+    } else {
+        for (uint32_t j = lane; j < n; j += DEC_THREADS) dec[j] = enc[j];
+    }
+}
+
+// K=7 (0x6d, 0x4f) hard-decision Viterbi, one lane per state.  enc: coded bits (punctured stream),
+// dec: n bytes.  dw: T = 8n+6 decision words of scratch.
+__device__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, unsigned long long *dw, int lane)
+{
+    const uint32_t Tn = 8 * n + 6;
+    const unsigned s = (unsigned)lane, b = s & 1, p0 = s >> 1, p1 = p0 | 32;
+    const unsigned sr0 = ((p0 << 1) | b) & 0x7f, sr1 = ((p1 << 1) | b) & 0x7f;
+    const unsigned eA0 = __popc(sr0 & 0x6d) & 1, eB0 = __popc(sr0 & 0x4f) & 1;
+    const unsigned eA1 = __popc(sr1 & 0x6d) & 1, eB1 = __popc(sr1 & 0x4f) & 1;
+    // puncturing rows (A, B) as bit masks over the column index
+    unsigned pa, pb;
+    switch (p) {
+    case 2: pa = 0x3; pb = 0x1; break;                 // 11 / 10
+    case 3: pa = 0x3; pb = 0x5; break;                 // 110 / 101
+    case 4: pa = 0xf; pb = 0x1; break;                 // 1111 / 1000
+    case 5: pa = 0xb; pb = 0x15; break;                // 11010 / 10101
+    case 6: pa = 0x17; pb = 0x29; break;               // 111010 / 100101
+    case 7: pa = 0x2f; pb = 0x51; break;               // 1111010 / 1000101
+    default: pa = 0x1; pb = 0x1; break;
+    }
+    uint32_t pm = (s == 0) ? 0u : (1u << 24);
+    for (uint32_t t0 = 0; t0 < Tn; t0 += 64) {
+        // lane l prepares the received code of step t0+l: bit0 = rA, bit1 = rB, bit2 = A present, bit3 = B present
+        unsigned code = 0;
+        {
+            const uint32_t t = t0 + lane;
+            if (t < Tn) {
+                const unsigned col = t % (unsigned)p;
+                const unsigned hasA = (pa >> col) & 1, hasB = (pb >> col) & 1;
+                uint32_t nb = (p == 1) ? 2 * t : t + (t + (unsigned)p - 1) / (unsigned)p;   // coded bits before step t
+                unsigned ra = 0, rb = 0;
+                if (hasA) { ra = getbit(enc, nb); nb++; }
+                if (hasB) { rb = getbit(enc, nb); }
+                code = ra | (rb << 1) | (hasA << 2) | (hasB << 3);
+            }
+        }
+        unsigned long long myword = 0;
+        const uint32_t nstep = min(64u, Tn - t0);
+        for (uint32_t u = 0; u < nstep; u++) {
+            const unsigned cu = __shfl(code, (int)u, 64);
+            const uint32_t m0 = __shfl(pm, (int)p0, 64), m1 = __shfl(pm, (int)p1, 64);
+            const unsigned ra = cu & 1, rb = (cu >> 1) & 1, hA = (cu >> 2) & 1, hB = (cu >> 3) & 1;
+            const uint32_t c0 = m0 + (hA & (eA0 ^ ra)) + (hB & (eB0 ^ rb));
+            const uint32_t c1 = m1 + (hA & (eA1 ^ ra)) + (hB & (eB1 ^ rb));
+            const bool d = c1 < c0;
+            pm = d ? c1 : c0;
+            const unsigned long long word = __ballot(d);
+            if ((uint32_t)lane == u) myword = word;
+        }
+        if (t0 + lane < Tn) dw[t0 + lane] = myword;
+    }
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < n; j += DEC_THREADS) dec[j] = 0;
+    __builtin_amdgcn_wave_barrier();
+    // traceback from state 0, 64 steps per register-resident chunk
+    unsigned st = 0;
+    const uint32_t nchunk = (Tn + 63) / 64;
+    for (uint32_t ch = nchunk; ch-- > 0;) {
+        const uint32_t t0 = ch * 64;
+        const uint32_t nstep = min(64u, Tn - t0);
+        const unsigned long long w = (t0 + lane < Tn) ? dw[t0 + lane] : 0ull;
+        const unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32);
+        unsigned long long bits = 0;                            // bit u = decoded input bit of step t0+u
+        for (uint32_t u = nstep; u-- > 0;) {
+            const unsigned lo = __shfl(wlo, (int)u, 64), hi = __shfl(whi, (int)u, 64);
+            const unsigned long long wu = ((unsigned long long)hi << 32) | lo;
+            bits |= (unsigned long long)(st & 1) << u;
+            st = (st >> 1) | ((unsigned)((wu >> st) & 1ull) << 5);
+        }
+        // steps t0 .. t0+63 are 8 output bytes (t0 is a multiple of 64): lane j<8 packs byte t0/8 + j
+        if (lane < 8) {
+            const uint32_t byte = t0 / 8 + lane;
+            if (byte < n) {
+                unsigned v = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) v = (v << 1) | (unsigned)((bits >> (8 * lane + k)) & 1ull);
+                dec[byte] = (uint8_t)v;
+            }
+        }
+    }
+}
+
+__device__ uint32_t crc_reflected(uint32_t poly_rev, uint32_t mask, const uint8_t *msg, uint32_t n)
+{
+    uint32_t key = mask;
+    for (uint32_t i = 0; i < n; i++) {
+        key ^= msg[i];
+#pragma unroll
+        for (int j = 0; j < 8; j++) key = (key >> 1) ^ (poly_rev & (0u - (key & 1u)));
+    }
+    return (~key) & mask;
+}
+
+extern "C" __global__ __launch_bounds__(DEC_THREADS)
+void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB,
+                      unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
+{
+    const FxPayJob job = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
+    const uint8_t *hs = hard + job.sym_off;
+    const unsigned bps = job.bps;
+    // 1. hard symbols -> packet bytes (MSB first)
+    for (uint32_t j = lane; j < job.l1; j += DEC_THREADS) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t k = 8 * j + b, sidx = k / bps, sb = bps - 1 - (k % bps);
+            v = (v << 1) | ((hs[sidx] >> sb) & 1u);
+        }
+        A[j] = (uint8_t)v;
+    }
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // 2. outer plan (fec1): de-interleave l1, decode -> l0 bytes
+    permute_bits(A, B, perm_arena + job.perm1_off, job.l1, lane);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    uint32_t status = 0;
+    const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
+    if (pc1) viterbi27(pc1, job.l0, B, A, dw_arena + job.dw_off, lane);
+    else block_fec_decode(job.fec1, job.l0, B, A, T, lane);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // 3. inner plan (fec0): de-interleave l0, decode -> k bytes
+    permute_bits(A, B, perm_arena + job.perm0_off, job.l0, lane);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    if (pc0) viterbi27(pc0, job.k, B, A, dw_arena + job.dw_off, lane);
+    else block_fec_decode(job.fec0, job.k, B, A, T, lane);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // 4. de-whiten, CRC, copy out
+    const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
+    for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; j < job.pay_len; j += DEC_THREADS) out[(size_t)job.out_off + j] = A[j];
+    if (lane == 0) {
+        const uint32_t cl = job.k - job.pay_len;
+        uint32_t rx = 0, key = 0;
+        for (uint32_t i = 0; i < cl; i++) rx = (rx << 8) | A[job.pay_len + i];
+        switch (job.check) {
+        case FX_CRC_CHECKSUM: { uint32_t s = 0; for (uint32_t i = 0; i < job.pay_len; i++) s += A[i]; key = (~s + 1u) & 0xff; break; }
+        case FX_CRC_8:  key = crc_reflected(0xE0u, 0xFFu, A, job.pay_len); break;
+        case FX_CRC_16: key = crc_reflected(0xA001u, 0xFFFFu, A, job.pay_len); break;
+        case FX_CRC_24: key = crc_reflected(0xD3B6BAu, 0xFFFFFFu, A, job.pay_len); break;
+        case FX_CRC_32: key = crc_reflected(0xEDB88320u, 0xFFFFFFFFu, A, job.pay_len); break;
+        default: key = 0; break;
+        }
+        res[blockIdx.x].payload_valid = (key == rx) ? 1u : 0u;
+        res[blockIdx.x].status = status;
+    }
+}

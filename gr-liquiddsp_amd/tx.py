@@ -1,0 +1,86 @@
+"""Frame generator (flex_tx counterpart, lib/flex_tx_impl.cc:191-209) and the synthetic IQ source of
+SURVEY.md section 8(d) / BASELINE.md: frames back to back with 256-sample gaps, per-stream CFO / phase /
+fractional delay, AWGN at Es/N0 = 20 dB.  Host-side numpy + the C-ABI flexframegen_* of libfxrx.so.
+"""
+import ctypes as C
+import numpy as np
+from . import _ffi
+
+CRC_24, CRC_32 = 5, 6
+# block-API index -> liquid enum (reference: lib/flex_tx_impl.cc:75-181)
+MOD_BY_INDEX = [1, 2, 3, 4, 9, 10, 11, 18, 27, 28, 29]
+INNER_BY_INDEX = [1, 11, 15, 17, 18, 19, 20]
+OUTER_BY_INDEX = [1, 7, 27, 4, 6, 8, 9, 10]
+
+
+class FrameGen:
+    def __init__(self, mod=2, fec0=11, fec1=1, check=CRC_24):
+        self.L = _ffi.lib()
+        self.props = _ffi.GenProps(check, fec0, fec1, mod)
+        self.h = self.L.flexframegen_create(C.byref(self.props))
+        if not self.h:
+            raise ValueError("unsupported frame properties")
+
+    def setprops(self, mod=None, fec0=None, fec1=None, check=None):
+        p = self.props
+        if mod is not None: p.mod_scheme = mod
+        if fec0 is not None: p.fec0 = fec0
+        if fec1 is not None: p.fec1 = fec1
+        if check is not None: p.check = check
+        if self.L.flexframegen_setprops(self.h, C.byref(p)) != 0:
+            raise ValueError("unsupported frame properties")
+
+    def frame(self, payload, header=None, dt=0.0):
+        payload = np.ascontiguousarray(payload, dtype=np.uint8)
+        hdr = np.zeros(14, np.uint8) if header is None else np.ascontiguousarray(header, dtype=np.uint8)
+        self.L.fxrx_gen_set_delay(self.h, float(dt))
+        self.L.flexframegen_assemble(self.h, hdr.ctypes.data, payload.ctypes.data, len(payload))
+        n = self.L.flexframegen_getframelen(self.h)
+        out = np.empty(n, np.complex64)
+        if self.L.flexframegen_write_samples(self.h, out.ctypes.data, n) != 1:
+            raise RuntimeError("flexframegen_write_samples failed")
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.flexframegen_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def synth_stream(n_samples, stream_id=0, mod=2, fec0=11, fec1=1, check=CRC_24, payload_len=1024, gap=256,
+                 snr_db=20.0, cfo=None, phase=None, delay=None, gain=1.0, lead=0, return_payloads=True):
+    """One synthetic IQ stream of exactly n_samples samples.
+
+    Payload bytes: MT19937(0x5EED + stream_id); channel draws: MT19937(0xC0FFEE + stream_id):
+    CFO ~ U(-0.05, 0.05) rad/sample, phase ~ U(-pi, pi), delay ~ U(-0.5, 0.5) sample, AWGN with
+    sigma^2 = 10^(-snr/10) per complex sample (unit-power signal), as in BASELINE.md section 3.
+    Returns (iq complex64, list of (start_index, payload bytes) of frames that fit entirely)."""
+    prng = np.random.RandomState((0x5EED + stream_id) & 0x7FFFFFFF)
+    crng = np.random.RandomState((0xC0FFEE + stream_id) & 0x7FFFFFFF)
+    cfo = crng.uniform(-0.05, 0.05) if cfo is None else cfo
+    phase = crng.uniform(-np.pi, np.pi) if phase is None else phase
+    delay = crng.uniform(-0.5, 0.5) if delay is None else delay
+    g = FrameGen(mod, fec0, fec1, check)
+    x = np.zeros(n_samples, np.complex64)
+    frames = []
+    p = lead
+    while True:
+        pl = prng.randint(0, 256, payload_len).astype(np.uint8)
+        fr = g.frame(pl, dt=delay)
+        if p + len(fr) > n_samples:
+            break
+        x[p:p + len(fr)] = fr
+        frames.append((p, pl.tobytes()))
+        p += len(fr) + gap
+    g.close()
+    n = np.arange(n_samples, dtype=np.float64)
+    rot = np.exp(1j * (cfo * n + phase)).astype(np.complex64)
+    x *= rot
+    if gain != 1.0:
+        x *= np.float32(gain)
+    sigma = np.sqrt(0.5 * 10.0 ** (-snr_db / 10.0))
+    noise = crng.standard_normal(2 * n_samples).astype(np.float32).view(np.complex64)
+    x += np.float32(sigma) * noise
+    return (x, frames) if return_payloads else x

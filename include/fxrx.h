@@ -1,0 +1,182 @@
+/*
+ * fxrx.h -- C ABI of libfxrx.so, the MI355X-native flexframe receive path.
+ *
+ * Two layers:
+ *
+ *  (1) DROP-IN NAMES.  The exact liquid-dsp entry points that gr::liquiddsp's blocks call, with
+ *      ABI-compatible signatures, so that gnuradio-liquiddsp can be linked against libfxrx.so for
+ *      this path.  Each declaration cites the reference line it serves.
+ *
+ *  (2) BATCHED API (fxrx_*).  Many independent IQ streams per call, device or host pointers,
+ *      results returned as plain records.  This is the throughput path (BASELINE configs 2-5);
+ *      the reference has no counterpart (one flexframesync handle per block instance,
+ *      /root/reference/lib/flex_rx_impl.cc:49).
+ *
+ * No torch / C++ types cross this boundary.  Nothing here throws; failures are status codes
+ * (or NULL handles) and fxrx_last_error().  The library needs a HIP device: every constructor
+ * fails loudly (NULL + error text) when none is usable -- there is no CPU fallback.
+ */
+#ifndef FXRX_H
+#define FXRX_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* liquid's `float complex` is two packed floats; gr_complex (std::complex<float>) likewise. */
+typedef struct { float re, im; } fx_complex;
+
+/* ------------------------------------------------------------------------------------------
+ * (1) drop-in names
+ * ------------------------------------------------------------------------------------------ */
+
+/* framesyncstats_s -- read at /root/reference/lib/flex_rx_impl.cc:195,198,218,232-234 */
+typedef struct {
+    float        evm;            /* error vector magnitude [dB] */
+    float        rssi;           /* received signal strength [dB] */
+    float        cfo;            /* carrier offset estimate [rad/sample] */
+    fx_complex  *framesyms;      /* payload symbols after carrier recovery */
+    unsigned int num_framesyms;
+    unsigned int mod_scheme;     /* LIQUID_MODEM_* value */
+    unsigned int mod_bps;
+    unsigned int check;          /* LIQUID_CRC_*   */
+    unsigned int fec0;           /* LIQUID_FEC_* (first / "inner" in the reference's naming) */
+    unsigned int fec1;           /* LIQUID_FEC_* (second / "outer") */
+} framesyncstats_s;
+
+/* callback type -- /root/reference/lib/flex_rx_impl.h:48-55 */
+typedef int (*framesync_callback)(unsigned char *header, int header_valid, unsigned char *payload,
+                                  unsigned int payload_len, int payload_valid, framesyncstats_s stats,
+                                  void *userdata);
+
+typedef struct fxrx_sync_s *flexframesync;
+
+/* /root/reference/lib/flex_rx_impl.cc:49 */
+flexframesync flexframesync_create(framesync_callback callback, void *userdata);
+/* /root/reference/lib/flex_rx_impl.cc:71 */
+void flexframesync_destroy(flexframesync q);
+/* /root/reference/lib/flex_rx_impl.cc:213.  Samples are queued and run through the GPU in blocks
+ * (fxrx_sync_set_block); at most ONE completed frame is handed to the callback per call, which is
+ * what the reference's work() loop can consume (it tests a single flag after each call, :216).
+ * Buffers passed to the callback stay valid until the next call on the same handle. */
+void flexframesync_execute(flexframesync q, fx_complex *x, unsigned int n);
+void flexframesync_reset(flexframesync q);
+/* extensions (additive): process whatever is queued now; tune the queue length (samples). */
+void fxrx_sync_flush(flexframesync q);
+void fxrx_sync_set_block(flexframesync q, unsigned int samples);
+void fxrx_sync_set_threshold(flexframesync q, float threshold);
+unsigned int fxrx_sync_pending(flexframesync q);     /* completed frames not yet delivered */
+
+/* m-sequence -- /root/reference/lib/frame_detector_cc_impl.cc:47,49,50,52 */
+typedef struct fxrx_mseq_s *msequence;
+msequence    msequence_create(unsigned int m, unsigned int g, unsigned int a);
+unsigned int msequence_advance(msequence ms);
+void         msequence_destroy(msequence ms);
+
+/* detector -- /root/reference/lib/frame_detector_cc_impl.cc:54,55,63,77,90-93 */
+#define LIQUID_FIRFILT_ARKAISER 7
+typedef struct fxrx_qdet_s *qdetector_cccf;
+/* Only the flexframe preamble configuration the reference uses is accepted:
+ * 64 symbols, ARKAISER, k=2, m=7, beta=0.3; anything else returns NULL. */
+qdetector_cccf qdetector_cccf_create_linear(fx_complex *sequence, unsigned int sequence_len, int ftype,
+                                            unsigned int k, unsigned int m, float beta);
+void   qdetector_cccf_destroy(qdetector_cccf q);
+void   qdetector_cccf_set_threshold(qdetector_cccf q, float threshold);
+/* Per-sample entry kept for link compatibility.  Samples are queued and searched on the GPU in
+ * blocks; every detection is reported exactly once (non-NULL = the 512 aligned samples), possibly
+ * some samples later than liquid would.  Block users should call fxrx_detect_* instead. */
+void  *qdetector_cccf_execute(qdetector_cccf q, fx_complex x);
+float  qdetector_cccf_get_tau(qdetector_cccf q);
+float  qdetector_cccf_get_gamma(qdetector_cccf q);
+float  qdetector_cccf_get_dphi(qdetector_cccf q);
+float  qdetector_cccf_get_phi(qdetector_cccf q);
+unsigned int qdetector_cccf_get_buf_len(qdetector_cccf q);
+
+/* frame generator (test / loopback source) -- /root/reference/lib/flex_tx_impl.cc:51,56,72,188,198-201 */
+typedef struct { unsigned int check, fec0, fec1, mod_scheme; } flexframegenprops_s;
+typedef struct fxrx_gen_s *flexframegen;
+int          flexframegenprops_init_default(flexframegenprops_s *props);
+flexframegen flexframegen_create(flexframegenprops_s *props);
+void         flexframegen_destroy(flexframegen q);
+int          flexframegen_setprops(flexframegen q, flexframegenprops_s *props);
+int          flexframegen_assemble(flexframegen q, const unsigned char *header, const unsigned char *payload,
+                                   unsigned int payload_len);
+unsigned int flexframegen_getframelen(flexframegen q);
+int          flexframegen_write_samples(flexframegen q, fx_complex *buffer, unsigned int buffer_len);
+/* extension: design the pulse with a fractional-sample delay (channel emulation in tests/bench) */
+void         fxrx_gen_set_delay(flexframegen q, float dt);
+
+/* ------------------------------------------------------------------------------------------
+ * (2) batched API
+ * ------------------------------------------------------------------------------------------ */
+enum { FXRX_MODE_FLEX_RX = 0, FXRX_MODE_DETECTOR = 1 };
+enum { FXRX_OK = 0, FXRX_ERR_ARG = -1, FXRX_ERR_HIP = -2, FXRX_ERR_NODEVICE = -3, FXRX_ERR_STATE = -4 };
+
+typedef struct {
+    int          device;         /* HIP device ordinal */
+    int          mode;           /* FXRX_MODE_* */
+    unsigned int n_streams;
+    float        threshold;      /* 0 -> default (0.5 flex_rx like liquid's flexframesync, 0.45 detector like
+                                    /root/reference/lib/frame_detector_cc_impl.cc:55) */
+    unsigned int segment_len;    /* speculation granularity in samples (0 -> auto) */
+    int          want_framesyms; /* copy payload symbols back to the host with each result */
+} fxrx_config;
+
+typedef struct {
+    unsigned int stream;
+    int64_t      start;          /* absolute sample index (since create/reset) of aligned sample 0 */
+    int          cfo_bin;        /* coarse CFO bin of the detector sweep */
+    float        rxy, tau, gamma, dphi, phi;
+    unsigned int pfb_index;
+    float        pilot_dphi, pilot_phi, pilot_gain;
+    int          header_valid, payload_valid;
+    unsigned char header[20];    /* 14 user bytes + 6 protocol bytes */
+    const unsigned char *payload; unsigned int payload_len;
+    const fx_complex *framesyms; unsigned int num_framesyms;   /* host pointer or NULL */
+    float        evm_db, rssi_db, cfo, evm_sum;
+    unsigned int mod_scheme, mod_bps, check, fec0, fec1;
+} fxrx_frame;
+
+typedef struct fxrx_ctx_s fxrx_ctx;
+
+const char *fxrx_last_error(void);
+const char *fxrx_version(void);
+int         fxrx_device_count(void);
+
+fxrx_ctx *fxrx_create(const fxrx_config *cfg);
+void      fxrx_destroy(fxrx_ctx *c);
+void      fxrx_reset(fxrx_ctx *c);
+
+/* Feed n_samples[s] new samples of every stream s.  iq[s] points at interleaved float32 (re,im);
+ * on_device != 0 means the pointers are HIP device pointers on cfg.device (zero copy when the
+ * stream has no carried-over tail).  Returns the number of results (frames, or detections in
+ * detector mode) now readable through fxrx_result(), or a negative FXRX_ERR_*.  Results and
+ * the buffers they point to stay valid until the next call on this context. */
+int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
+int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out);
+/* device-resident payload symbols / hard decisions of the last call (NULL if none) */
+const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n_symbols);
+
+typedef struct {
+    double   walk_ms, paymf_ms, paypll_ms, paydec_ms, total_ms;   /* HIP-event times of the last call */
+    uint64_t hops, walk_jobs, repairs, frames, payload_symbols, samples;
+} fxrx_timing;
+int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
+/* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
+void *fxrx_stream(const fxrx_ctx *c);
+
+/* batched frame generator: one frame -> samples (host) */
+unsigned int fxrx_gen_frame_len(unsigned int mod_scheme, unsigned int check, unsigned int fec0, unsigned int fec1,
+                                unsigned int payload_len);
+
+/* block-API index maps of the reference (lib/flex_tx_impl.cc:75-181, lib/flex_rx_impl.cc:74-179); -1 = unsupported */
+int fxrx_mod_from_index(int idx);   int fxrx_mod_to_index(unsigned int mod_scheme);
+int fxrx_inner_from_index(int idx); int fxrx_inner_to_index(unsigned int fec);
+int fxrx_outer_from_index(int idx); int fxrx_outer_to_index(unsigned int fec);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
