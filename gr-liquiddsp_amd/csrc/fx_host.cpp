@@ -282,6 +282,7 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
         size_t cur = first_job[s]; uint32_t m = 0;
         FxWalkResult R = c->h_res.p[cur]; const FxFrame *F = c->h_frames.p + c->jobs[cur].frame_base;
         std::vector<FxFrame> repair_frames; float splice_rxy = -1.0f;
+        bool spliced = false; int64_t tpos = 0, tfloor = 0; bool tfresh = true;   // true-chain state at the last splice
         for (;;) {
             c->timing.hops += R.hops;
             uint32_t nf = R.n_frames;
@@ -307,7 +308,15 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
                 F = repair_frames.data(); m = 0;
                 continue;
             }
-            if (last || R.exit_code != FX_EXIT_STOP || !R.has_handoff) { ch.pos = R.pos; ch.floor_ = R.floor; ch.fresh = R.fresh != 0; break; }
+            if (last || R.exit_code != FX_EXIT_STOP || !R.has_handoff) {
+                if (spliced && nf <= m) {
+                    // the spliced-in walker added nothing complete (its matched frame runs past the data):
+                    // its own hop state is speculative, so resume from the true chain's hand-off hop instead
+                    ch.pos = tpos; ch.floor_ = tfloor; ch.fresh = tfresh;
+                } else { ch.pos = R.pos; ch.floor_ = R.floor; ch.fresh = R.fresh != 0; }
+                break;
+            }
+            spliced = false;
             // hand-off: look the target up in the next segment's speculative list
             // (segments the true walker crossed without a detection cannot hold the target: skip them)
             size_t nxt = cur + 1;
@@ -316,7 +325,10 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
             uint32_t found = UINT32_MAX;
             for (uint32_t i = 0; i < RN.n_frames; i++)
                 if ((FN[i].flags & FX_FLAG_EXACT) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; break; }
-            if (found != UINT32_MAX) { splice_rxy = R.handoff_rxy; cur = nxt; m = found; R = RN; F = FN; continue; }
+            if (found != UINT32_MAX) {
+                splice_rxy = R.handoff_rxy; spliced = true; tpos = R.pos; tfloor = R.floor; tfresh = R.fresh != 0;
+                cur = nxt; m = found; R = RN; F = FN; continue;
+            }
             // repair: walk the next segment from the true state
             FxWalkJob j = c->jobs[nxt]; j.start = R.pos; j.fresh = R.fresh; j.floor = R.floor; j.prelock = 0;
             j.frame_base = repair_base; j.max_frames = repair_cap;
