@@ -47,6 +47,14 @@ FX_DEV uint32_t rad2u32(float rad)
     return (uint32_t)(long long)t;
 }
 
+// PLL increments: clamp, then a plain 32-bit convert (same value as the wrapping form for |x| < pi)
+FX_DEV uint32_t rad2u32s(float rad)
+{
+    float t = rintf(rad * 683565248.0f);
+    t = fminf(fmaxf(t, -2147483520.0f), 2147483520.0f);
+    return (uint32_t)(int)t;
+}
+
 FX_DEV void sincos_u32(uint32_t th, const float2 *sc, float &c, float &s)
 {
     const float2 t = sc[th >> 22];

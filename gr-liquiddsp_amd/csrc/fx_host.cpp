@@ -23,7 +23,8 @@
 
 extern "C" __global__ void fx_walk_kernel(const FxWalkJob *, FxWalkResult *, FxFrame *, const FxTables *);
 extern "C" __global__ void fx_paymf_kernel(const FxPayJob *, const uint32_t *, const uint32_t *, float2 *, const FxTables *);
-extern "C" __global__ void fx_paypll_kernel(const FxPayJob *, uint32_t, const float2 *, float2 *, uint8_t *, FxPayResult *, const FxTables *);
+extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+                                       const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T);
 extern "C" __global__ void fx_paydec_kernel(const FxPayJob *, const uint8_t *, const uint32_t *, uint8_t *, uint8_t *,
                                             unsigned long long *, uint8_t *, FxPayResult *, const FxTables *);
 
@@ -94,8 +95,8 @@ struct fxrx_ctx_s {
     PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames;
     // payload
     std::map<PlanKey, PlanDev> plans; std::vector<uint32_t> perm_host; DevBuf<uint32_t> d_perm; size_t perm_uploaded = 0;
-    std::vector<FxPayJob> pjobs; std::vector<uint32_t> blk_job, blk_c0;
-    DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0;
+    std::vector<FxPayJob> pjobs; std::vector<uint32_t> blk_job, blk_c0, pll_idx;
+    DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0, d_pll_idx;
     DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_out; DevBuf<unsigned long long> d_dw;
     DevBuf<FxPayResult> d_pres; PinBuf<FxPayResult> h_pres; PinBuf<uint8_t> h_out; PinBuf<float2> h_framesyms;
     uint64_t n_syms_last = 0;
@@ -367,7 +368,7 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
                 j.byte_off = (uint32_t)byte_total; j.dw_off = (uint32_t)dw_total; j.out_off = (uint32_t)out_total;
                 o.pjob = (int)c->pjobs.size();
                 for (uint32_t c0 = 0; c0 < j.nsym; c0 += 1024) { c->blk_job.push_back((uint32_t)o.pjob); c->blk_c0.push_back(c0); }
-                sym_total += j.nsym;
+                sym_total += (j.nsym + 7) & ~7u;                      // 8-symbol granules: 64-byte block I/O in the PLL kernel
                 byte_total += (uint64_t)((std::max(j.l1, j.k) + 8 + 15) & ~15u);
                 dw_total += 8ull * std::max(j.l0, j.k) + 6 + 64;
                 out_total += (j.pay_len + 15) & ~15u;
@@ -390,7 +391,7 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
             c->perm_uploaded = c->perm_host.size();
         }
         if (c->d_pjobs.reserve(NP) || c->d_blk_job.reserve(c->blk_job.size()) || c->d_blk_c0.reserve(c->blk_c0.size()) ||
-            c->d_symraw.reserve(sym_total) || c->d_framesyms.reserve(sym_total) || c->d_hard.reserve(sym_total + 16) ||
+            c->d_symraw.reserve(sym_total + 8) || c->d_framesyms.reserve(sym_total + 8) || c->d_hard.reserve(sym_total + 64) ||
             c->d_bufA.reserve(byte_total) || c->d_bufB.reserve(byte_total) || c->d_dw.reserve(dw_total) ||
             c->d_out.reserve(out_total + 16) || c->d_pres.reserve(NP) || c->h_pres.reserve(NP) || c->h_out.reserve(out_total + 16)) return FXRX_ERR_HIP;
         HIP_OK(hipMemcpyAsync(c->d_pjobs.p, c->pjobs.data(), NP * sizeof(FxPayJob), hipMemcpyHostToDevice, c->stream));
@@ -400,9 +401,19 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
                            c->d_pjobs.p, c->d_blk_job.p, c->d_blk_c0.p, c->d_symraw.p, c->d_tables);
         HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(c->ev[3], c->stream));
-        hipLaunchKernelGGL(fx_paypll_kernel, dim3((unsigned)((NP + 63) / 64)), dim3(64), 0, c->stream,
-                           c->d_pjobs.p, (uint32_t)NP, c->d_symraw.p, c->d_framesyms.p, c->d_hard.p, c->d_pres.p, c->d_tables);
-        HIP_OK(hipGetLastError());
+        // one PLL grid per modulation scheme present (demodulator resolved at compile time)
+        {
+            std::map<unsigned, std::vector<uint32_t>> by_ms;
+            for (size_t i = 0; i < NP; i++) by_ms[c->pjobs[i].ms].push_back((uint32_t)i);
+            c->pll_idx.clear();
+            std::vector<std::tuple<unsigned, size_t, size_t>> groups;
+            for (auto &kv : by_ms) { groups.emplace_back(kv.first, c->pll_idx.size(), kv.second.size()); c->pll_idx.insert(c->pll_idx.end(), kv.second.begin(), kv.second.end()); }
+            if (c->d_pll_idx.reserve(NP)) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(c->d_pll_idx.p, c->pll_idx.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            for (auto &g : groups)
+                HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), c->stream, c->d_pjobs.p, c->d_pll_idx.p + std::get<1>(g),
+                                        c->d_symraw.p, c->d_framesyms.p, c->d_hard.p, c->d_pres.p, c->d_tables));
+        }
         HIP_OK(hipEventRecord(c->ev[4], c->stream));
         hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, c->stream,
                            c->d_pjobs.p, c->d_hard.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_dw.p, c->d_out.p, c->d_pres.p, c->d_tables);

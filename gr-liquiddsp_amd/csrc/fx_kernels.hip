@@ -486,34 +486,101 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
 }
 
 // ===================================================================== payload: PLL + hard demod (lane per frame)
+// The decision-directed loop is a strict symbol-to-symbol recurrence, so a frame is one lane.  What the
+// lane can do is keep the recurrence's critical path short: raw symbols are fetched eight at a time
+// (one block ahead, 64 contiguous bytes per lane), results leave as 16-byte stores, the sin/cos table sits
+// in LDS and the four PSK2/PSK4 constellation points in registers.
 #define PLL_THREADS 64
+#define PLL_BLK     8
 
-extern "C" __global__ __launch_bounds__(PLL_THREADS)
-void fx_paypll_kernel(const FxPayJob *jobs, uint32_t njobs, const float2 *sym_raw, float2 *framesyms, uint8_t *hard,
-                      FxPayResult *res, const FxTables *T)
+__device__ __forceinline__ void pll_load8(const float4 *p, float4 b[4]) { b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = p[3]; }
+
+// One instantiation per modulation scheme: the demodulator is resolved at compile time, so the loop body is
+// straight-line code (the host launches one grid per scheme present in the batch, over an index list).
+template <int MS>
+__device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const float2 *sc, float2 q0, float2 q1, float2 q2, float2 q3,
+                                             float2 &xh, float &pe)
+{
+    if constexpr (MS == FX_MODEM_PSK2 || MS == FX_MODEM_PSK4) {
+        unsigned idx, pi4;
+        if constexpr (MS == FX_MODEM_PSK2) { idx = r.x > 0.0f ? 0u : 1u; pi4 = 2u * idx; }
+        else { idx = (fabsf(r.x) >= fabsf(r.y)) ? (r.x > 0.0f ? 0u : 2u) : (r.y > 0.0f ? 1u : 3u); pi4 = idx; }
+        xh = pi4 == 0 ? q0 : (pi4 == 1 ? q1 : (pi4 == 2 ? q2 : q3));
+        float pr = fmaf(r.x, xh.x, r.y * xh.y);
+        float pim = fmaf(r.y, xh.x, -(r.x * xh.y));
+        pe = atan2c(pim, pr);
+        return gray_enc(idx);
+    } else {
+        return modem_demod((unsigned)MS, modem_bps((unsigned)MS), r, prev, sc, xh, pe);
+    }
+}
+
+template <int MS>
+__global__ __launch_bounds__(PLL_THREADS)
+void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, const float2 *sym_raw, float2 *framesyms,
+                      uint8_t *hard, FxPayResult *res, const FxTables *T)
 {
     __shared__ float2 sc[1024];
     for (int i = threadIdx.x; i < 1024; i += PLL_THREADS) sc[i] = T->sc[i];
     __syncthreads();
-    const uint32_t f = blockIdx.x * PLL_THREADS + threadIdx.x;
-    if (f >= njobs) return;
+    const uint32_t li = blockIdx.x * PLL_THREADS + threadIdx.x;
+    if (li >= njobs) return;
+    const uint32_t f = job_idx[li];
     const FxPayJob job = jobs[f];
-    const float2 *in = sym_raw + job.sym_off;
-    float2 *out = framesyms + job.sym_off;
-    uint8_t *hd = hard + job.sym_off;
+    const float4 *in = reinterpret_cast<const float4 *>(sym_raw + job.sym_off);      // sym_off is a multiple of 8
+    float4 *out = reinterpret_cast<float4 *>(framesyms + job.sym_off);
+    uint2 *hd = reinterpret_cast<uint2 *>(hard + job.sym_off);
     uint32_t th = job.pll_th; float fq = job.pll_f, evm = 0.0f; unsigned prev = 0;
-    const unsigned ms = job.ms, bps = job.bps;
-    for (uint32_t c = 0; c < job.nsym; c++) {
-        float2 r = derot(in[c], th, sc), xh; float pe;
-        unsigned s = modem_demod(ms, bps, r, prev, sc, xh, pe);
-        float dr = r.x - xh.x, di = r.y - xh.y;
-        evm += fmaf(dr, dr, di * di);
-        fq += pe * 1e-4f;
-        th += rad2u32(pe * 0.01f);
-        th += rad2u32(fq);
-        out[c] = r; hd[c] = (uint8_t)s;
+    const unsigned nsym = job.nsym;
+    const float2 q0 = sc[0], q1 = sc[256], q2 = sc[512], q3 = sc[768];
+    const uint32_t nblk = (nsym + PLL_BLK - 1) / PLL_BLK;
+    float4 cur[4], nxt[4];
+    if (nblk) pll_load8(in, cur);
+    for (uint32_t b = 0; b < nblk; b++) {
+        if (b + 1 < nblk) pll_load8(in + 4 * (b + 1), nxt);
+        const unsigned live = min(PLL_BLK, (int)(nsym - b * PLL_BLK));          // < 8 only in the last block
+        float rr[2 * PLL_BLK]; unsigned h0 = 0, h1 = 0;
+#pragma unroll
+        for (int k = 0; k < PLL_BLK; k++) {
+            const float4 v4 = cur[k >> 1];
+            const float2 y = (k & 1) ? make_float2(v4.z, v4.w) : make_float2(v4.x, v4.y);
+            float2 r = derot(y, th, sc), xh; float pe;
+            unsigned pv = prev;
+            const unsigned s = pll_demod<MS>(r, pv, sc, q0, q1, q2, q3, xh, pe);
+            if ((unsigned)k < live) {                                          // tail of the last block: state frozen
+                float dr = r.x - xh.x, di = r.y - xh.y;
+                evm += fmaf(dr, dr, di * di);
+                fq += pe * 1e-4f;
+                th += rad2u32s(pe * 0.01f);
+                th += rad2u32s(fq);
+                prev = pv;
+            }
+            rr[2 * k] = r.x; rr[2 * k + 1] = r.y;
+            if (k < 4) h0 |= s << (8 * k); else h1 |= s << (8 * (k - 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) out[4 * b + k] = make_float4(rr[4 * k], rr[4 * k + 1], rr[4 * k + 2], rr[4 * k + 3]);
+        hd[b] = make_uint2(h0, h1);
+#pragma unroll
+        for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
     res[f].evm_sum = evm;
+}
+
+// host-side launcher (lives here so that the template instantiations stay in this translation unit)
+extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+                                       const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
+{
+    const dim3 grid((njobs + PLL_THREADS - 1) / PLL_THREADS), block(PLL_THREADS);
+#define FX_PLL_CASE(M) case M: hipLaunchKernelGGL(fx_paypll_kernel<M>, grid, block, 0, st, jobs, job_idx, njobs, sym_raw, framesyms, hard, res, T); break;
+    switch (ms) {
+        FX_PLL_CASE(FX_MODEM_PSK2) FX_PLL_CASE(FX_MODEM_PSK4) FX_PLL_CASE(FX_MODEM_PSK8) FX_PLL_CASE(FX_MODEM_PSK16)
+        FX_PLL_CASE(FX_MODEM_DPSK2) FX_PLL_CASE(FX_MODEM_DPSK4) FX_PLL_CASE(FX_MODEM_DPSK8) FX_PLL_CASE(FX_MODEM_ASK4)
+        FX_PLL_CASE(FX_MODEM_QAM16) FX_PLL_CASE(FX_MODEM_QAM32) FX_PLL_CASE(FX_MODEM_QAM64) FX_PLL_CASE(FX_MODEM_QPSK)
+    default: return hipErrorInvalidValue;
+    }
+#undef FX_PLL_CASE
+    return hipGetLastError();
 }
 
 // ===================================================================== payload: packet decode (wave per frame)

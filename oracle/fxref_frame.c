@@ -454,8 +454,8 @@ static void sync_on_symbol(fxr_sync *q, fxr_c32 y)
     float dr = r.re - xh.re, di = r.im - xh.im;
     q->evm_sum += fmaf(dr, dr, di * di);
     q->pll_f += pe * 1e-4f;
-    q->pll_th += fxr_rad2u32(pe * 0.01f);
-    q->pll_th += fxr_rad2u32(q->pll_f);
+    q->pll_th += fxr_rad2u32s(pe * 0.01f);
+    q->pll_th += fxr_rad2u32s(q->pll_f);
     q->pay_sym[q->pay_counter] = r; q->pay_hard[q->pay_counter] = (uint8_t)s;
     if (++q->pay_counter == q->pay_sym_len) sync_decode_payload(q);
 }

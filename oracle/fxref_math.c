@@ -41,6 +41,14 @@ uint32_t fxr_rad2u32(float rad)
     return (uint32_t)(int64_t)t;
 }
 
+/* PLL increments are tiny; clamp so that a 32-bit convert is exact and saturation-free on any input */
+uint32_t fxr_rad2u32s(float rad)
+{
+    float t = rintf(rad * 683565248.0f);
+    t = fminf(fmaxf(t, -2147483520.0f), 2147483520.0f);
+    return (uint32_t)(int32_t)t;
+}
+
 /* cos/sin of a 32-bit phase: table on the top 10 bits, series on the remaining 22 */
 void fxr_sincos_u32(uint32_t th, float *c, float *s)
 {
