@@ -93,7 +93,7 @@ struct FxWalkResult {
     uint32_t fresh;
     uint32_t has_handoff;   // hand-off target valid
     int64_t  handoff_start; int32_t handoff_offset; uint32_t hops;
-    float    handoff_rxy; uint32_t pad_;
+    float    handoff_rxy; uint32_t hops_cheap;
 };
 
 // ---- payload stage records ----

@@ -13,10 +13,12 @@ struct FxTables {
     float2   sc[1024];       // (cos, sin)(2 pi k / 1024)
     float2   S[512];         // FFT of the zero-padded detector template
     float2   s[FX_S_LEN];    // detector template (RRC-shaped p/n preamble)
+    float2   TD[512];        // FFT of td[k] = s[k+1] conj(s[k]) (coarse pre-lock scan only)
     float2   pilots[16];
     float    proto[FX_PROTO_LEN + 3];
     float    s2sum;          // sum |s|^2
-    float    pad_[3];
+    float    td2sum;         // sum |td|^2
+    float    pad_[2];
     uint16_t perm54[FX_HDR_ENC * 8];   // bit gather tables of the header de-interleavers
     uint16_t perm27[FX_HDR_E0 * 8];
     uint8_t  h84dec[256];

@@ -120,6 +120,21 @@ int upload_tables(fxrx_ctx_s *c)
     for (int i = 0; i < FX_HDR_PILOTS; i++) t->pilots[i] = make_float2(H.pilots[i].re, H.pilots[i].im);
     std::memcpy(t->proto, H.proto, sizeof H.proto);
     t->s2sum = H.s2sum;
+    {   // differential template for the speculative walkers' coarse scan
+        fx::cf td[512]; std::memset(td, 0, sizeof td);
+        float e = 0.0f, mr = 0.0f, mi = 0.0f;
+        const int nd = FX_S_LEN - 1;
+        for (int k = 0; k < nd; k++) {
+            td[k].re = H.s[k + 1].re * H.s[k].re + H.s[k + 1].im * H.s[k].im;
+            td[k].im = H.s[k + 1].im * H.s[k].re - H.s[k + 1].re * H.s[k].im;
+            mr += td[k].re; mi += td[k].im;
+        }
+        mr /= (float)nd; mi /= (float)nd;                       // zero-mean over its support (see the kernel)
+        for (int k = 0; k < nd; k++) { td[k].re -= mr; td[k].im -= mi; e += td[k].re * td[k].re + td[k].im * td[k].im; }
+        fx::cf TD[512]; fx::hfft::fft512(td, TD, H.tw);
+        for (int i = 0; i < 512; i++) t->TD[i] = make_float2(TD[i].re, TD[i].im);
+        t->td2sum = e;
+    }
     for (size_t i = 0; i < H.perm54.size(); i++) t->perm54[i] = (uint16_t)H.perm54[i];
     for (size_t i = 0; i < H.perm27.size(); i++) t->perm27[i] = (uint16_t)H.perm27[i];
     std::memcpy(t->h84dec, B.h84_dec, 256); std::memcpy(t->sdcol, B.sd_col, 64);
@@ -285,7 +300,7 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
         std::vector<FxFrame> repair_frames; float splice_rxy = -1.0f;
         bool spliced = false; int64_t tpos = 0, tfloor = 0; bool tfresh = true;   // true-chain state at the last splice
         for (;;) {
-            c->timing.hops += R.hops;
+            c->timing.hops += R.hops; c->timing.hops_cheap += R.hops_cheap;
             uint32_t nf = R.n_frames;
             if (R.exit_code == FX_EXIT_PAYLOAD && nf > 0) nf--;            // incomplete frame: redo next call
             for (uint32_t i = m; i < nf; i++) {

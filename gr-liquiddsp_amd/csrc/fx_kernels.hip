@@ -65,7 +65,7 @@ __device__ __forceinline__ float2 block_csum256(float2 v, WalkLds &L, int lane, 
 // samples below `floor` (before the last synchroniser reset) and outside the stream read as zero
 __device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_, int64_t n)
 {
-    return (p >= floor_ && p < n) ? x[p] : make_float2(0.0f, 0.0f);
+    return (p >= floor_ && p >= 0 && p < n) ? x[p] : make_float2(0.0f, 0.0f);
 }
 
 // header: 54 received bytes -> 20 header bytes + CRC verdict.  Single thread, ~2k integer ops.
@@ -106,7 +106,7 @@ __device__ int decode_header_bytes(WalkLds &L, const FxTables *T, uint8_t *out)
     return key == rx;
 }
 
-extern "C" __global__ __launch_bounds__(WALK_THREADS)
+extern "C" __global__ __launch_bounds__(WALK_THREADS, 2)
 void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, const FxTables *T)
 {
     __shared__ WalkLds L;
@@ -122,7 +122,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 
     int64_t pos = job.start, floor_ = job.floor;
     bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
-    uint32_t nfr = 0, hops = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
+    uint32_t nfr = 0, hops = 0, hops_cheap = 0, exact_left = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
     int64_t ho_start = 0; int32_t ho_off = 0; float ho_rxy = 0.0f;
     float x2_0 = 0.0f;
     const float s2sum = T->s2sum;
@@ -134,13 +134,70 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 
     for (;;) {
         if (pos >= job.stop && !in_handoff) {
-            if (job.handoff) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }
+            // a speculative walker that never locked has nothing to hand off (its state is not the chain's)
+            if (job.handoff && locked) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }
         }
         if (pos + FX_HOP > n) { exit_code = FX_EXIT_NEED_DATA; break; }
 
-        // ------------------------------------------------------------ SEEK: one 256-sample hop
         float2 nw = xv(x, pos + tid, floor_, n);
         L.win[FX_HOP + tid] = nw;
+
+        // ------------------------------------------------------------ pre-lock coarse scan (speculative walkers only)
+        // Until a speculative walker has locked onto the chain, nothing it produces is kept, so it may look
+        // for its first preamble any way it likes.  A CFO-blind differential correlator needs 2 FFTs per hop
+        // instead of the 50 of the real detector: d[i] = w[i+1] conj(w[i]) against the zero-mean td[k] = s[k+1] conj(s[k]).
+        // A hit at lag l re-arms the exact detector (fresh) one hop before the candidate.
+        if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0) {
+            __syncthreads();
+            hops_cheap++;
+            float2 d0 = cmulc(L.win[tid + 1], L.win[tid]);
+            float2 d1 = (tid < 255) ? cmulc(L.win[tid + 257], L.win[tid + 256]) : make_float2(0.0f, 0.0f);
+            L.X[tid] = d0; L.X[tid + 256] = d1;
+            // energy of d about its mean: oversampled signals give d a large DC term that is not information
+            float ed = block_sum256(cm2(d0) + cm2(d1), L, lane, wave);
+            const float2 dsum = block_csum256(cadd(d0, d1), L, lane, wave);
+            ed -= cm2(dsum) * (1.0f / (float)FX_NFFT);
+            if (wave == 0) {
+                float2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = L.X[lane + 64 * q];
+                fft512_wave(a, L.scr[0], lane, twA, twB);
+                const int kb = (lane >> 3) + 8 * (lane & 7);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 8; t++) { float2 y = cmulc(a[t], T->TD[kb + 64 * t]); L.X[kb + 64 * t] = make_float2(y.y, y.x); }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = L.X[lane + 64 * q];
+                fft512_wave(a, L.scr[0], lane, twA, twB);
+                float bv = -1.0f; uint32_t bk = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t k = (uint32_t)kb + 64 * t;
+                    const float m = cm2(a[t]);
+                    if (k < FX_NFFT - FX_S_LEN && m > bv) { bv = m; bk = k; }
+                }
+                wave_argmax(bv, bk);
+                if (lane == 0) { L.f[4] = bv; L.u[8] = bk; }
+            }
+            __syncthreads();
+            const float cpk = L.f[4]; const uint32_t cl = L.u[8];
+            if (cpk > 0.06f * ed * T->td2sum * (float)FX_NFFT * (float)FX_NFFT && ed > 0.0f) {
+                // candidate preamble at p: restart the exact detector, fresh, one hop earlier
+                const int64_t p = pos - FX_HOP + (int64_t)cl;
+                pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
+                L.win[tid] = make_float2(0.0f, 0.0f);
+                __syncthreads();
+                continue;
+            }
+            L.win[tid] = nw;
+            pos += FX_HOP; fresh = false;
+            __syncthreads();
+            continue;
+        }
+        if (exact_left) exact_left--;
+
+        // ------------------------------------------------------------ SEEK: one 256-sample hop
         const float x2_1 = block_sum256(cm2(nw), L, lane, wave);     // barriers inside publish win[]
         hops++;
         const float g0 = sqrtf(x2_0 + x2_1) * sqrtf((float)FX_S_LEN / (float)FX_NFFT);
@@ -443,7 +500,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         FxWalkResult r;
         r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
         r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
-        r.handoff_rxy = ho_rxy; r.pad_ = 0;
+        r.handoff_rxy = ho_rxy; r.hops_cheap = hops_cheap;
         results[blockIdx.x] = r;
     }
 }
