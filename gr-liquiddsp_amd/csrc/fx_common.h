@@ -121,4 +121,5 @@ struct FxPayResult {
     uint32_t payload_valid;
     uint32_t status;        // 0 ok, 1 unsupported FEC on device
     uint32_t pad_;
+    uint32_t stamp[8];      // diagnostic builds (-DFX_STAMPS): shader-clock deltas of the decode phases
 };

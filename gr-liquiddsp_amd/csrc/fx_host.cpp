@@ -385,7 +385,7 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
                 for (uint32_t c0 = 0; c0 < j.nsym; c0 += 1024) { c->blk_job.push_back((uint32_t)o.pjob); c->blk_c0.push_back(c0); }
                 sym_total += (j.nsym + 7) & ~7u;                      // 8-symbol granules: 64-byte block I/O in the PLL kernel
                 byte_total += (uint64_t)((std::max(j.l1, j.k) + 8 + 15) & ~15u);
-                dw_total += 8ull * std::max(j.l0, j.k) + 6 + 64;
+                dw_total += ((8ull * std::max(j.l0, j.k) + 6 + 63) & ~63ull) + 64;   // whole 64-step chunks, lane-major
                 out_total += (j.pay_len + 15) & ~15u;
                 c->pjobs.push_back(j);
                 o.f.mod_scheme = f.ms; o.f.mod_bps = j.bps; o.f.check = f.check; o.f.fec0 = f.fec0; o.f.fec1 = f.fec1;
@@ -474,6 +474,13 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
     (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->timing.paydec_ms = ms;
     (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); c->timing.total_ms = ms;
     return (int)c->out.size();
+}
+
+// diagnostic: decode-phase shader-clock deltas of payload job i (zeros unless built with -DFX_STAMPS)
+int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8])
+{
+    if (!c || i >= c->pjobs.size()) return FXRX_ERR_ARG;
+    std::memcpy(out, c->h_pres.p[i].stamp, 8 * sizeof(uint32_t)); return 0;
 }
 
 int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out)

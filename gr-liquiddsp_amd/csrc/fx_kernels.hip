@@ -646,7 +646,7 @@ extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, hipStream_t 
 __device__ __forceinline__ unsigned getbit(const uint8_t *b, uint32_t i) { return (b[i >> 3] >> (7 - (i & 7))) & 1u; }
 
 // gather-permute `nbytes` bytes bit by bit: dst bit i = src bit perm[i]
-__device__ void permute_bits(const uint8_t *src, uint8_t *dst, const uint32_t *perm, uint32_t nbytes, int lane)
+__device__ __forceinline__ void permute_bits(const uint8_t *src, uint8_t *dst, const uint32_t *perm, uint32_t nbytes, int lane)
 {
     for (uint32_t j = lane; j < nbytes; j += DEC_THREADS) {
         unsigned v = 0;
@@ -656,7 +656,7 @@ __device__ void permute_bits(const uint8_t *src, uint8_t *dst, const uint32_t *p
     }
 }
 
-__device__ void block_fec_decode(unsigned fs, uint32_t n, const uint8_t *enc, uint8_t *dec, const FxTables *T, int lane)
+__device__ __forceinline__ void block_fec_decode(unsigned fs, uint32_t n, const uint8_t *enc, uint8_t *dec, const FxTables *T, int lane)
 {
     if (fs == FX_FEC_HAMMING84) {
         for (uint32_t j = lane; j < n; j += DEC_THREADS)
@@ -678,17 +678,67 @@ __device__ void block_fec_decode(unsigned fs, uint32_t n, const uint8_t *enc, ui
     }
 }
 
-// K=7 (0x6d, 0x4f) hard-decision Viterbi, one lane per state.  enc: coded bits (punctured stream),
-// dec: n bytes.  dw: T = 8n+6 decision words of scratch.
-__device__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, unsigned long long *dw, int lane)
+// K=7 (0x6d, 0x4f) hard-decision Viterbi, one lane per state, exchange-free of LDS.
+//
+// A shift-register trellis is a perfect shuffle: state p feeds rotl(p,1) (input bit = p's old MSB) and
+// its butterfly partner is p ^ 32.  Keeping state s of time t in lane rotr(s, t mod 6) makes every
+// successor land in the lane its predecessor came from, so one add-compare-select step needs exactly one
+// XOR-lane exchange, with masks cycling 32,16,8,4,2,1 -- permlane32_swap, permlane16_swap and DPP row
+// operations, no ds_bpermute.  Metrics, tie rule (equal -> predecessor with MSB 0) and traceback are the
+// plain algorithm's; only the lane numbering rotates.
+//   enc: coded bits (punctured stream), dec: n bytes, dw: T = 8n+6 decision words of scratch.
+template <int PH> __device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane)
 {
+    if constexpr (PH == 0) { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
+    else if constexpr (PH == 1) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
+    else if constexpr (PH == 2) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, false), 0x141, 0xf, 0xf, false);
+    else if constexpr (PH == 3) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
+    else if constexpr (PH == 4) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);
+    else return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
+}
+
+// One add-compare-select step at rotation phase PH.  Metrics are kept doubled (P = 2*metric, even) so that a
+// parity tag can break ties and carry the decision: own key = P + 2*bm_own + hi, partner key = P' + 2*bm_oth
+// + (1 - hi); the keys never tie, the smaller wins with "equal metrics -> predecessor with MSB 0", and its
+// LSB is the decision bit (1 = survivor came from the MSB-1 predecessor).  2*bm comes from one popcount of
+// (expected ^ received) on bit-doubled code bits; the partner's branch expects the complement (both
+// generator polynomials have their end taps set), so 2*bm_oth = 2*nbits - 2*bm_own.
+template <int PH, bool PUNCT>
+__device__ __forceinline__ void acs_step(uint32_t &P, unsigned code, uint32_t u, const unsigned (&eown)[6], int lane, unsigned &hist)
+{
+    const unsigned cu = (unsigned)__builtin_amdgcn_readlane((int)code, (int)u);       // R4 | H4<<4 | (2*nbits)<<8
+    const unsigned hi = ((unsigned)lane >> (5 - PH)) & 1u;
+    unsigned t = eown[PH] ^ (cu & 15u);
+    unsigned nb2 = 4u;
+    if constexpr (PUNCT) { t &= (cu >> 4) & 15u; nb2 = cu >> 8; }
+    const unsigned q = __popc(t);                                                      // 2 * bm_own
+    const uint32_t x = (nb2 + 1u - hi) - q;                                            // off the metric's critical path
+    const uint32_t Po = lane_xor<PH>(P, lane);
+    const uint32_t k_own = P + (q + hi);
+    const uint32_t k_oth = Po + x;
+    const uint32_t m = min(k_own, k_oth);
+    hist = (hist << 1) | (m & 1u);
+    P = m & ~1u;
+}
+
+template <bool PUNCT>
+__device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, unsigned long long *dw, int lane, uint32_t *stamp_fwd)
+{
+#ifdef FX_STAMPS
+    unsigned long long tv0_ = __builtin_readcyclecounter();
+#endif
     const uint32_t Tn = 8 * n + 6;
-    const unsigned s = (unsigned)lane, b = s & 1, p0 = s >> 1, p1 = p0 | 32;
-    const unsigned sr0 = ((p0 << 1) | b) & 0x7f, sr1 = ((p1 << 1) | b) & 0x7f;
-    const unsigned eA0 = __popc(sr0 & 0x6d) & 1, eB0 = __popc(sr0 & 0x4f) & 1;
-    const unsigned eA1 = __popc(sr1 & 0x6d) & 1, eB1 = __popc(sr1 & 0x4f) & 1;
-    // puncturing rows (A, B) as bit masks over the column index
-    unsigned pa, pb;
+    // bit-doubled expected code bits (A in bits 0-1, B in bits 2-3) of the branch that ends in this lane's own
+    // predecessor role, for each rotation phase
+    unsigned eown[6];
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) {
+        const unsigned st = (((unsigned)lane << ph) | ((unsigned)lane >> (6 - ph))) & 63u;   // state held at phase ph
+        const unsigned b = st >> 5;                                                           // = hi: this lane is the MSB-1 side
+        const unsigned sr = ((st << 1) | b) & 0x7f;                                           // own branch: (st) -> rotl(st,1)
+        eown[ph] = ((__popc(sr & 0x6d) & 1) ? 3u : 0u) | ((__popc(sr & 0x4f) & 1) ? 12u : 0u);
+    }
+    unsigned pa, pb;                                       // puncturing rows (A, B) as bit masks over the column
     switch (p) {
     case 2: pa = 0x3; pb = 0x1; break;                 // 11 / 10
     case 3: pa = 0x3; pb = 0x5; break;                 // 110 / 101
@@ -698,55 +748,79 @@ __device__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, u
     case 7: pa = 0x2f; pb = 0x51; break;               // 1111010 / 1000101
     default: pa = 0x1; pb = 0x1; break;
     }
-    uint32_t pm = (s == 0) ? 0u : (1u << 24);
+    // received code word of step t: R4 | H4 << 4 | (2 * bits present) << 8
+    auto prep = [&](uint32_t t) -> unsigned {
+        if (t >= Tn) return 0u;
+        const unsigned col = t % (unsigned)p;
+        const unsigned hasA = (pa >> col) & 1, hasB = (pb >> col) & 1;
+        uint32_t nb = (p == 1) ? 2 * t : t + (t + (unsigned)p - 1) / (unsigned)p;       // coded bits before step t
+        unsigned ra = 0, rb = 0;
+        if (hasA) { ra = getbit(enc, nb); nb++; }
+        if (hasB) { rb = getbit(enc, nb); }
+        return (ra * 3u) | (rb * 12u) | ((hasA * 3u | hasB * 12u) << 4) | ((2u * (hasA + hasB)) << 8);
+    };
+    uint32_t P = (lane == 0) ? 0u : (1u << 25);            // state 0 sits in lane 0 at every phase
+    unsigned code_next = prep(lane);
     for (uint32_t t0 = 0; t0 < Tn; t0 += 64) {
-        // lane l prepares the received code of step t0+l: bit0 = rA, bit1 = rB, bit2 = A present, bit3 = B present
-        unsigned code = 0;
-        {
-            const uint32_t t = t0 + lane;
-            if (t < Tn) {
-                const unsigned col = t % (unsigned)p;
-                const unsigned hasA = (pa >> col) & 1, hasB = (pb >> col) & 1;
-                uint32_t nb = (p == 1) ? 2 * t : t + (t + (unsigned)p - 1) / (unsigned)p;   // coded bits before step t
-                unsigned ra = 0, rb = 0;
-                if (hasA) { ra = getbit(enc, nb); nb++; }
-                if (hasB) { rb = getbit(enc, nb); }
-                code = ra | (rb << 1) | (hasA << 2) | (hasB << 3);
+        const unsigned code = code_next;
+        code_next = prep(t0 + 64 + lane);                  // next chunk's loads fly while this chunk computes
+        const uint32_t nstep = min(64u, Tn - t0);
+        unsigned hist[2] = { 0u, 0u };
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t ub = 32u * h, ue = min(nstep, ub + 32u);
+            uint32_t u = ub;
+            while (u < ue) {
+                switch ((t0 + u) % 6) {
+                case 0:
+                    if (u + 6 <= ue) {
+                        acs_step<0, PUNCT>(P, code, u, eown, lane, hist[h]);     acs_step<1, PUNCT>(P, code, u + 1, eown, lane, hist[h]);
+                        acs_step<2, PUNCT>(P, code, u + 2, eown, lane, hist[h]); acs_step<3, PUNCT>(P, code, u + 3, eown, lane, hist[h]);
+                        acs_step<4, PUNCT>(P, code, u + 4, eown, lane, hist[h]); acs_step<5, PUNCT>(P, code, u + 5, eown, lane, hist[h]);
+                        u += 6;
+                    } else { acs_step<0, PUNCT>(P, code, u, eown, lane, hist[h]); u++; }
+                    break;
+                case 1: acs_step<1, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
+                case 2: acs_step<2, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
+                case 3: acs_step<3, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
+                case 4: acs_step<4, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
+                default: acs_step<5, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
+                }
             }
         }
-        unsigned long long myword = 0;
-        const uint32_t nstep = min(64u, Tn - t0);
-        for (uint32_t u = 0; u < nstep; u++) {
-            const unsigned cu = __shfl(code, (int)u, 64);
-            const uint32_t m0 = __shfl(pm, (int)p0, 64), m1 = __shfl(pm, (int)p1, 64);
-            const unsigned ra = cu & 1, rb = (cu >> 1) & 1, hA = (cu >> 2) & 1, hB = (cu >> 3) & 1;
-            const uint32_t c0 = m0 + (hA & (eA0 ^ ra)) + (hB & (eB0 ^ rb));
-            const uint32_t c1 = m1 + (hA & (eA1 ^ ra)) + (hB & (eB1 ^ rb));
-            const bool d = c1 < c0;
-            pm = d ? c1 : c0;
-            const unsigned long long word = __ballot(d);
-            if ((uint32_t)lane == u) myword = word;
-        }
-        if (t0 + lane < Tn) dw[t0 + lane] = myword;
+        // lane-major history: word [chunk][lane] holds this lane's decisions, newest step in bit 0 of each half
+        dw[t0 + lane] = ((unsigned long long)hist[1] << 32) | hist[0];
     }
     __threadfence_block();
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < n; j += DEC_THREADS) dec[j] = 0;
-    __builtin_amdgcn_wave_barrier();
-    // traceback from state 0, 64 steps per register-resident chunk
+#ifdef FX_STAMPS
+    if (lane == 0 && stamp_fwd) *stamp_fwd = (uint32_t)(__builtin_readcyclecounter() - tv0_);
+#endif
+    // traceback from state 0 (wave-uniform, scalar); history words of the next chunk down are prefetched
     unsigned st = 0;
     const uint32_t nchunk = (Tn + 63) / 64;
+    unsigned long long w_next = dw[(nchunk - 1) * 64 + lane];
     for (uint32_t ch = nchunk; ch-- > 0;) {
         const uint32_t t0 = ch * 64;
         const uint32_t nstep = min(64u, Tn - t0);
-        const unsigned long long w = (t0 + lane < Tn) ? dw[t0 + lane] : 0ull;
+        const unsigned long long w = w_next;
+        if (ch > 0) w_next = dw[(ch - 1) * 64 + lane];
         const unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32);
         unsigned long long bits = 0;                            // bit u = decoded input bit of step t0+u
-        for (uint32_t u = nstep; u-- > 0;) {
-            const unsigned lo = __shfl(wlo, (int)u, 64), hi = __shfl(whi, (int)u, 64);
-            const unsigned long long wu = ((unsigned long long)hi << 32) | lo;
-            bits |= (unsigned long long)(st & 1) << u;
-            st = (st >> 1) | ((unsigned)((wu >> st) & 1ull) << 5);
+        unsigned r = (t0 + nstep) % 6;                          // (t+1) mod 6 for t = t0+nstep-1
+#pragma unroll
+        for (int h = 1; h >= 0; h--) {
+            const uint32_t ub = 32u * h;
+            if (nstep <= ub) continue;
+            const uint32_t nh = min(nstep - ub, 32u);
+            const unsigned hw = h ? whi : wlo;
+            for (uint32_t uh = nh; uh-- > 0;) {
+                const unsigned ln = ((st >> r) | (st << (6 - r))) & 63u;     // state st of time t+1 lives in lane rotr(st, (t+1) mod 6)
+                const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)hw, (int)ln);
+                bits |= (unsigned long long)(st & 1) << (ub + uh);
+                st = (st >> 1) | (((word >> (nh - 1 - uh)) & 1u) << 5);
+                r = r ? r - 1 : 5;
+            }
         }
         // steps t0 .. t0+63 are 8 output bytes (t0 is a multiple of 64): lane j<8 packs byte t0/8 + j
         if (lane < 8) {
@@ -761,7 +835,7 @@ __device__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, u
     }
 }
 
-__device__ uint32_t crc_reflected(uint32_t poly_rev, uint32_t mask, const uint8_t *msg, uint32_t n)
+__device__ __forceinline__ uint32_t crc_reflected(uint32_t poly_rev, uint32_t mask, const uint8_t *msg, uint32_t n)
 {
     uint32_t key = mask;
     for (uint32_t i = 0; i < n; i++) {
@@ -772,15 +846,29 @@ __device__ uint32_t crc_reflected(uint32_t poly_rev, uint32_t mask, const uint8_
     return (~key) & mask;
 }
 
+#ifdef FX_STAMPS
+#define FX_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) res[blockIdx.x].stamp[i] = (uint32_t)(t_ - t_prev); t_prev = t_; } while (0)
+#define FX_STAMP_INIT unsigned long long t_prev = __builtin_readcyclecounter()
+#else
+#define FX_STAMP(i) do { } while (0)
+#define FX_STAMP_INIT do { } while (0)
+#endif
+
 extern "C" __global__ __launch_bounds__(DEC_THREADS)
 void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB,
                       unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
 {
-    const FxPayJob job = jobs[blockIdx.x];
+    FxPayJob job = jobs[blockIdx.x];
+    // one wave per frame: pin the loop bounds into SGPRs so that every loop below is scalar-controlled
+    job.l0 = __builtin_amdgcn_readfirstlane(job.l0); job.l1 = __builtin_amdgcn_readfirstlane(job.l1);
+    job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
+    job.fec0 = __builtin_amdgcn_readfirstlane(job.fec0); job.fec1 = __builtin_amdgcn_readfirstlane(job.fec1);
+    job.bps = __builtin_amdgcn_readfirstlane(job.bps); job.check = __builtin_amdgcn_readfirstlane(job.check);
     const int lane = threadIdx.x;
     uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
     const uint8_t *hs = hard + job.sym_off;
     const unsigned bps = job.bps;
+    FX_STAMP_INIT;
     // 1. hard symbols -> packet bytes (MSB first)
     for (uint32_t j = lane; j < job.l1; j += DEC_THREADS) {
         unsigned v = 0;
@@ -792,20 +880,27 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
         A[j] = (uint8_t)v;
     }
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    FX_STAMP(0);
     // 2. outer plan (fec1): de-interleave l1, decode -> l0 bytes
     permute_bits(A, B, perm_arena + job.perm1_off, job.l1, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    FX_STAMP(1);
     uint32_t status = 0;
     const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
-    if (pc1) viterbi27(pc1, job.l0, B, A, dw_arena + job.dw_off, lane);
+    if (pc1 == 1) viterbi27<false>(1, job.l0, B, A, dw_arena + job.dw_off, lane, nullptr);
+    else if (pc1) viterbi27<true>(pc1, job.l0, B, A, dw_arena + job.dw_off, lane, nullptr);
     else block_fec_decode(job.fec1, job.l0, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    FX_STAMP(2);
     // 3. inner plan (fec0): de-interleave l0, decode -> k bytes
     permute_bits(A, B, perm_arena + job.perm0_off, job.l0, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    if (pc0) viterbi27(pc0, job.k, B, A, dw_arena + job.dw_off, lane);
+    FX_STAMP(3);
+    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, lane, &res[blockIdx.x].stamp[6]);
+    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, lane, &res[blockIdx.x].stamp[6]);
     else block_fec_decode(job.fec0, job.k, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    FX_STAMP(4);
     // 4. de-whiten, CRC, copy out
     const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
     for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
@@ -826,4 +921,5 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
         res[blockIdx.x].payload_valid = (key == rx) ? 1u : 0u;
         res[blockIdx.x].status = status;
     }
+    FX_STAMP(5);
 }
