@@ -67,7 +67,7 @@ EXPORTS = [
     "flexframegenprops_init_default", "flexframegen_create", "flexframegen_destroy", "flexframegen_setprops",
     "flexframegen_assemble", "flexframegen_getframelen", "flexframegen_write_samples", "fxrx_gen_set_delay",
     "fxrx_last_error", "fxrx_version", "fxrx_device_count", "fxrx_create", "fxrx_destroy", "fxrx_reset",
-    "fxrx_process", "fxrx_result", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
+    "fxrx_process", "fxrx_result", "fxrx_set_depth", "fxrx_submit", "fxrx_collect", "fxrx_debug_stamps", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
     "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
     "fxrx_outer_from_index", "fxrx_outer_to_index",
 ]
@@ -108,6 +108,11 @@ def lib():
     L.fxrx_process.restype = C.c_int
     L.fxrx_process.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
     L.fxrx_result.restype = C.c_int; L.fxrx_result.argtypes = [C.c_void_p, C.c_uint, C.POINTER(Frame)]
+    L.fxrx_submit.restype = C.c_int
+    L.fxrx_submit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
+    L.fxrx_collect.restype = C.c_int; L.fxrx_collect.argtypes = [C.c_void_p]
+    L.fxrx_set_depth.restype = C.c_int; L.fxrx_set_depth.argtypes = [C.c_void_p, C.c_uint]
+    L.fxrx_debug_stamps.restype = C.c_int; L.fxrx_debug_stamps.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint32 * 8)]
     L.fxrx_device_framesyms.restype = C.c_void_p; L.fxrx_device_framesyms.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fxrx_last_timing.restype = C.c_int; L.fxrx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.fxrx_stream.restype = C.c_void_p; L.fxrx_stream.argtypes = [C.c_void_p]

@@ -83,27 +83,40 @@ struct PlanDev { fx::PacketPlan plan; uint32_t perm0_off, perm1_off; };
 
 }  // namespace
 
-struct fxrx_ctx_s {
-    fxrx_config cfg{};
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[6]{};
-    FxTables *d_tables = nullptr;
-    std::vector<StreamState> st;
-    // walker
-    std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
-    DevBuf<FxWalkJob> d_jobs; DevBuf<FxWalkResult> d_res; DevBuf<FxFrame> d_frames;
-    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames;
-    // payload
-    std::map<PlanKey, PlanDev> plans; std::vector<uint32_t> perm_host; DevBuf<uint32_t> d_perm; size_t perm_uploaded = 0;
+struct Out { fxrx_frame f; int pjob; };
+
+// One in-flight block's payload stage: its own arenas, staging and result buffers, so that the PLL of
+// block n, the packet decode of block n-1 and the walk of block n+1 can run concurrently on three streams.
+struct Slot {
     std::vector<FxPayJob> pjobs; std::vector<uint32_t> blk_job, blk_c0, pll_idx;
     DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0, d_pll_idx;
     DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_out; DevBuf<unsigned long long> d_dw;
     DevBuf<FxPayResult> d_pres; PinBuf<FxPayResult> h_pres; PinBuf<uint8_t> h_out; PinBuf<float2> h_framesyms;
-    uint64_t n_syms_last = 0;
-    // results
-    struct Out { fxrx_frame f; int pjob; };
+    PinBuf<FxPayJob> hp_pjobs; PinBuf<uint32_t> hp_idx;          // pinned staging: H2D really is asynchronous
     std::vector<Out> out;
+    uint64_t n_syms = 0;
     fxrx_timing timing{};
+    hipEvent_t ev_mf0 = nullptr, ev_mf1 = nullptr, ev_pll1 = nullptr, ev_dec1 = nullptr, ev_done = nullptr;
+    bool busy = false;
+};
+
+struct fxrx_ctx_s {
+    fxrx_config cfg{};
+    hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
+    hipStream_t stream_p = nullptr;      // P: payload PLL
+    hipStream_t stream_d = nullptr;      // D: packet decode + result copies
+    hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;
+    FxTables *d_tables = nullptr;
+    std::vector<StreamState> st;
+    // walker (host-synchronised per submit, so one set suffices)
+    std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
+    DevBuf<FxWalkJob> d_jobs; DevBuf<FxWalkResult> d_res; DevBuf<FxFrame> d_frames;
+    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames; PinBuf<FxWalkJob> hp_jobs;
+    // packet plans (shared, append-only)
+    std::map<PlanKey, PlanDev> plans; std::vector<uint32_t> perm_host; DevBuf<uint32_t> d_perm; size_t perm_uploaded = 0;
+    // pipeline
+    std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
+    Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
 };
 
 namespace {
@@ -159,7 +172,8 @@ inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)(seg / 512 + 8);
 
 int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
 {
-    HIP_OK(hipMemcpyAsync(c->d_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob), hipMemcpyHostToDevice, c->stream));
+    std::memcpy(c->hp_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob));
+    HIP_OK(hipMemcpyAsync(c->d_jobs.p + first, c->hp_jobs.p + first, count * sizeof(FxWalkJob), hipMemcpyHostToDevice, c->stream));
     hipLaunchKernelGGL(fx_walk_kernel, dim3((unsigned)count), dim3(256), 0, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables);
     HIP_OK(hipGetLastError());
     return 0;
@@ -174,6 +188,15 @@ const char *fxrx_last_error(void) { return g_err.c_str(); }
 const char *fxrx_version(void) { return "fxrx 0.1 (gfx950)"; }
 int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 
+static int make_slot(fxrx_ctx_s *c)
+{
+    std::unique_ptr<Slot> s(new Slot);
+    hipEvent_t *ev[5] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll1, &s->ev_dec1, &s->ev_done };
+    for (auto e : ev) HIP_OK(hipEventCreate(e));
+    c->slots.push_back(std::move(s));
+    return 0;
+}
+
 fxrx_ctx *fxrx_create(const fxrx_config *cfg)
 {
     if (!cfg || cfg->n_streams == 0) { set_err("fxrx_create: bad config"); return nullptr; }
@@ -185,44 +208,76 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
-    for (auto &e : c->ev) if (hipEventCreate(&e) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
+    hipStream_t *ss[3] = { &c->stream, &c->stream_p, &c->stream_d };
+    for (auto s : ss) if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+    if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
     if (upload_tables(c.get()) != 0) return nullptr;
     c->st.resize(cfg->n_streams);
+    if (make_slot(c.get()) != 0) return nullptr;
     return c.release();
+}
+
+static void sync_all(fxrx_ctx_s *c)
+{
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream_p) (void)hipStreamSynchronize(c->stream_p);
+    if (c->stream_d) (void)hipStreamSynchronize(c->stream_d);
 }
 
 void fxrx_destroy(fxrx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    sync_all(c);
+    for (auto &s : c->slots) {
+        hipEvent_t ev[5] = { s->ev_mf0, s->ev_mf1, s->ev_pll1, s->ev_dec1, s->ev_done };
+        for (auto e : ev) if (e) (void)hipEventDestroy(e);
+    }
+    if (c->ev_w0) (void)hipEventDestroy(c->ev_w0);
+    if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
     if (c->d_tables) (void)hipFree(c->d_tables);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    hipStream_t ss[3] = { c->stream, c->stream_p, c->stream_d };
+    for (auto s : ss) if (s) (void)hipStreamDestroy(s);
     delete c;
 }
 
+// forget all per-stream state (position, carried tail).  In-flight blocks are unaffected.
 void fxrx_reset(fxrx_ctx *c)
 {
     if (!c) return;
     for (auto &s : c->st) { s.carry_len = 0; s.base = 0; s.pos = 0; s.floor_ = 0; s.fresh = true; }
-    c->out.clear();
+}
+
+int fxrx_set_depth(fxrx_ctx *c, unsigned int depth)
+{
+    if (!c || depth == 0 || depth > 8) return FXRX_ERR_ARG;
+    if (c->inflight) { set_err("fxrx_set_depth: blocks in flight"); return FXRX_ERR_STATE; }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    while (c->slots.size() < depth) if (make_slot(c) != 0) return FXRX_ERR_HIP;
+    c->depth = depth; c->head = c->tail = 0;
+    return 0;
 }
 
 void *fxrx_stream(const fxrx_ctx *c) { return c ? (void *)c->stream : nullptr; }
 
-int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t) { if (!c || !t) return FXRX_ERR_ARG; *t = c->timing; return 0; }
+int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t) { if (!c || !t || !c->last) return FXRX_ERR_ARG; *t = c->last->timing; return 0; }
 
-const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n) { if (!c) return nullptr; if (n) *n = c->n_syms_last; return c->n_syms_last ? c->d_framesyms.p : nullptr; }
-
-int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
+const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
 {
-    if (!c || !iq || !n_samples) { set_err("fxrx_process: null argument"); return FXRX_ERR_ARG; }
+    if (!c || !c->last) return nullptr;
+    if (n) *n = c->last->n_syms;
+    return c->last->n_syms ? c->last->d_framesyms.p : nullptr;
+}
+
+int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
+{
+    if (!c || !iq || !n_samples) { set_err("fxrx_submit: null argument"); return FXRX_ERR_ARG; }
+    if (c->inflight >= c->depth) { set_err("fxrx_submit: pipeline full, call fxrx_collect first"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
+    Slot &sl = *c->slots[c->head];
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
-    c->out.clear(); c->timing = fxrx_timing{};
+    sl.out.clear(); sl.timing = fxrx_timing{};
 
     // ---- 1. per-stream work buffers: [tail of previous call | new samples] ----
     std::vector<const float2 *> xs(NS); std::vector<int64_t> ns(NS);
@@ -237,7 +292,7 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
         if (nn) HIP_OK(hipMemcpyAsync(S.work.p + S.carry_len, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
         xs[s] = S.work.p; ns[s] = (int64_t)(S.carry_len + nn);
     }
-    c->timing.samples = total_new;
+    sl.timing.samples = total_new;
 
     // ---- 2. walk jobs: cut every stream into segments ----
     uint64_t seg = c->cfg.segment_len;
@@ -278,17 +333,17 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
     // one spare job slot + frame region for repairs
     const uint32_t repair_base = frame_slots; const uint32_t repair_cap = seg_frames_cap(4 * seg);
     frame_slots += repair_cap;
-    if (c->d_jobs.reserve(NJ + 1) || c->d_res.reserve(NJ + 1) || c->h_res.reserve(NJ + 1) ||
+    if (c->d_jobs.reserve(NJ + 1) || c->d_res.reserve(NJ + 1) || c->h_res.reserve(NJ + 1) || c->hp_jobs.reserve(NJ + 1) ||
         c->d_frames.reserve(frame_slots) || c->h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
     c->jobs.resize(NJ + 1);
 
-    HIP_OK(hipEventRecord(c->ev[0], c->stream));
+    HIP_OK(hipEventRecord(c->ev_w0, c->stream));
     if (launch_walk(c, 0, NJ)) return FXRX_ERR_HIP;
-    HIP_OK(hipEventRecord(c->ev[1], c->stream));
+    HIP_OK(hipEventRecord(c->ev_w1, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_res.p, c->d_res.p, NJ * sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_frames.p, c->d_frames.p, (size_t)repair_base * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipStreamSynchronize(c->stream));
-    c->timing.walk_jobs = NJ;
+    sl.timing.walk_jobs = NJ;
 
     // ---- 3. stitch: per stream, splice speculative lists into the sequential chain ----
     struct Chain { std::vector<FxFrame> frames; int64_t pos, floor_; bool fresh; };
@@ -299,8 +354,21 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
         FxWalkResult R = c->h_res.p[cur]; const FxFrame *F = c->h_frames.p + c->jobs[cur].frame_base;
         std::vector<FxFrame> repair_frames; float splice_rxy = -1.0f;
         bool spliced = false; int64_t tpos = 0, tfloor = 0; bool tfresh = true;   // true-chain state at the last splice
+        auto run_repair = [&](const FxWalkJob &tmpl, const FxWalkResult &from) -> int {
+            FxWalkJob j = tmpl; j.start = from.pos; j.fresh = from.fresh; j.floor = from.floor; j.prelock = 0;
+            j.frame_base = repair_base; j.max_frames = repair_cap;
+            c->jobs[NJ] = j;
+            if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(c->h_res.p + NJ, c->d_res.p + NJ, sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipMemcpyAsync(c->h_frames.p + repair_base, c->d_frames.p + repair_base, (size_t)repair_cap * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            sl.timing.repairs++;
+            R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
+            F = repair_frames.data(); m = 0;
+            return 0;
+        };
         for (;;) {
-            c->timing.hops += R.hops; c->timing.hops_cheap += R.hops_cheap;
+            sl.timing.hops += R.hops; sl.timing.hops_cheap += R.hops_cheap;
             uint32_t nf = R.n_frames;
             if (R.exit_code == FX_EXIT_PAYLOAD && nf > 0) nf--;            // incomplete frame: redo next call
             for (uint32_t i = m; i < nf; i++) {
@@ -310,18 +378,9 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
             }
             splice_rxy = -1.0f;
             const bool last = (cur + 1 == first_job[s + 1]);
-            if (R.exit_code == FX_EXIT_TABLE_FULL) {
-                // continue the same segment from where the table filled up
-                FxWalkJob j = c->jobs[cur]; j.start = R.pos; j.fresh = R.fresh; j.floor = R.floor; j.prelock = 0;
-                j.frame_base = repair_base; j.max_frames = repair_cap;
-                c->jobs[NJ] = j;
-                if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
-                HIP_OK(hipMemcpyAsync(c->h_res.p + NJ, c->d_res.p + NJ, sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
-                HIP_OK(hipMemcpyAsync(c->h_frames.p + repair_base, c->d_frames.p + repair_base, (size_t)repair_cap * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
-                HIP_OK(hipStreamSynchronize(c->stream));
-                c->timing.repairs++;
-                R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
-                F = repair_frames.data(); m = 0;
+            if (R.exit_code == FX_EXIT_TABLE_FULL) {                       // continue the same segment where the table filled up
+                const FxWalkResult from = R;
+                if (run_repair(c->jobs[cur], from)) return FXRX_ERR_HIP;
                 continue;
             }
             if (last || R.exit_code != FX_EXIT_STOP || !R.has_handoff) {
@@ -346,25 +405,21 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
                 cur = nxt; m = found; R = RN; F = FN; continue;
             }
             // repair: walk the next segment from the true state
-            FxWalkJob j = c->jobs[nxt]; j.start = R.pos; j.fresh = R.fresh; j.floor = R.floor; j.prelock = 0;
-            j.frame_base = repair_base; j.max_frames = repair_cap;
-            c->jobs[NJ] = j;
-            if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(c->h_res.p + NJ, c->d_res.p + NJ, sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
-            HIP_OK(hipMemcpyAsync(c->h_frames.p + repair_base, c->d_frames.p + repair_base, (size_t)repair_cap * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
-            HIP_OK(hipStreamSynchronize(c->stream));
-            c->timing.repairs++;
-            R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
-            F = repair_frames.data(); m = 0; cur = nxt;
+            const FxWalkResult from = R;
+            if (run_repair(c->jobs[nxt], from)) return FXRX_ERR_HIP;
+            cur = nxt;
         }
     }
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev_w0, c->ev_w1); sl.timing.walk_ms = ms;
 
     // ---- 4. payload jobs ----
-    c->pjobs.clear(); c->blk_job.clear(); c->blk_c0.clear();
+    sl.pjobs.clear(); sl.blk_job.clear(); sl.blk_c0.clear();
     uint64_t sym_total = 0, byte_total = 0, dw_total = 0, out_total = 0;
+    const size_t perm_before = c->perm_host.size();
     for (unsigned s = 0; s < NS; s++) {
         for (const FxFrame &f : chains[s].frames) {
-            fxrx_ctx_s::Out o{}; std::memset(&o.f, 0, sizeof o.f);
+            Out o{}; std::memset(&o.f, 0, sizeof o.f);
             o.f.stream = s; o.f.start = c->st[s].base + f.start; o.f.cfo_bin = f.offset;
             o.f.rxy = f.rxy; o.f.tau = f.tau; o.f.gamma = f.gamma; o.f.dphi = f.dphi; o.f.phi = f.phi; o.f.pfb_index = f.pfb;
             o.f.pilot_dphi = f.pilot_dphi; o.f.pilot_phi = f.pilot_phi; o.f.pilot_gain = f.pilot_gain;
@@ -381,70 +436,80 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
                 j.pay_len = f.pay_len; j.check = f.check; j.fec0 = f.fec0; j.fec1 = f.fec1;
                 j.k = pd.plan.k; j.l0 = pd.plan.l0; j.l1 = pd.plan.l1; j.perm0_off = pd.perm0_off; j.perm1_off = pd.perm1_off;
                 j.byte_off = (uint32_t)byte_total; j.dw_off = (uint32_t)dw_total; j.out_off = (uint32_t)out_total;
-                o.pjob = (int)c->pjobs.size();
-                for (uint32_t c0 = 0; c0 < j.nsym; c0 += 1024) { c->blk_job.push_back((uint32_t)o.pjob); c->blk_c0.push_back(c0); }
+                o.pjob = (int)sl.pjobs.size();
+                for (uint32_t c0 = 0; c0 < j.nsym; c0 += 1024) { sl.blk_job.push_back((uint32_t)o.pjob); sl.blk_c0.push_back(c0); }
                 sym_total += (j.nsym + 7) & ~7u;                      // 8-symbol granules: 64-byte block I/O in the PLL kernel
                 byte_total += (uint64_t)((std::max(j.l1, j.k) + 8 + 15) & ~15u);
                 dw_total += ((8ull * std::max(j.l0, j.k) + 6 + 63) & ~63ull) + 64;   // whole 64-step chunks, lane-major
                 out_total += (j.pay_len + 15) & ~15u;
-                c->pjobs.push_back(j);
+                sl.pjobs.push_back(j);
                 o.f.mod_scheme = f.ms; o.f.mod_bps = j.bps; o.f.check = f.check; o.f.fec0 = f.fec0; o.f.fec1 = f.fec1;
                 o.f.payload_len = f.pay_len; o.f.num_framesyms = f.pay_sym_len;
             }
-            c->out.push_back(o);
+            sl.out.push_back(o);
         }
     }
-    c->timing.frames = c->out.size(); c->timing.payload_symbols = sym_total; c->n_syms_last = sym_total;
-    if (sym_total >= (1ull << 32) || byte_total >= (1ull << 32) || dw_total >= (1ull << 32)) { set_err("fxrx_process: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
+    sl.timing.frames = sl.out.size(); sl.timing.payload_symbols = sym_total; sl.n_syms = sym_total;
+    if (sym_total >= (1ull << 32) || byte_total >= (1ull << 32) || dw_total >= (1ull << 32)) { set_err("fxrx_submit: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
 
-    const size_t NP = c->pjobs.size();
-    HIP_OK(hipEventRecord(c->ev[2], c->stream));
+    const size_t NP = sl.pjobs.size();
     if (NP) {
-        if (c->perm_uploaded != c->perm_host.size()) {
+        if (c->perm_host.size() != perm_before || c->perm_uploaded != c->perm_host.size()) {
+            // a packet configuration seen for the first time: the shared gather-table arena grows.  Rare; drain
+            // everything so that no in-flight decode still reads the old allocation.
+            sync_all(c);
             if (c->d_perm.reserve(c->perm_host.size())) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(c->d_perm.p, c->perm_host.data(), c->perm_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+            HIP_OK(hipMemcpy(c->d_perm.p, c->perm_host.data(), c->perm_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
             c->perm_uploaded = c->perm_host.size();
         }
-        if (c->d_pjobs.reserve(NP) || c->d_blk_job.reserve(c->blk_job.size()) || c->d_blk_c0.reserve(c->blk_c0.size()) ||
-            c->d_symraw.reserve(sym_total + 8) || c->d_framesyms.reserve(sym_total + 8) || c->d_hard.reserve(sym_total + 64) ||
-            c->d_bufA.reserve(byte_total) || c->d_bufB.reserve(byte_total) || c->d_dw.reserve(dw_total) ||
-            c->d_out.reserve(out_total + 16) || c->d_pres.reserve(NP) || c->h_pres.reserve(NP) || c->h_out.reserve(out_total + 16)) return FXRX_ERR_HIP;
-        HIP_OK(hipMemcpyAsync(c->d_pjobs.p, c->pjobs.data(), NP * sizeof(FxPayJob), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(c->d_blk_job.p, c->blk_job.data(), c->blk_job.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(c->d_blk_c0.p, c->blk_c0.data(), c->blk_c0.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(fx_paymf_kernel, dim3((unsigned)c->blk_job.size()), dim3(256), 0, c->stream,
-                           c->d_pjobs.p, c->d_blk_job.p, c->d_blk_c0.p, c->d_symraw.p, c->d_tables);
+        const size_t NB = sl.blk_job.size();
+        if (sl.d_pjobs.reserve(NP) || sl.hp_pjobs.reserve(NP) || sl.d_blk_job.reserve(NB) || sl.d_blk_c0.reserve(NB) ||
+            sl.d_pll_idx.reserve(NP) || sl.hp_idx.reserve(2 * NB + NP) ||
+            sl.d_symraw.reserve(sym_total + 8) || sl.d_framesyms.reserve(sym_total + 8) || sl.d_hard.reserve(sym_total + 64) ||
+            sl.d_bufA.reserve(byte_total) || sl.d_bufB.reserve(byte_total) || sl.d_dw.reserve(dw_total) ||
+            sl.d_out.reserve(out_total + 16) || sl.d_pres.reserve(NP) || sl.h_pres.reserve(NP) || sl.h_out.reserve(out_total + 16)) return FXRX_ERR_HIP;
+        // group PLL jobs by modulation scheme (one grid per scheme: demodulator resolved at compile time)
+        std::map<unsigned, std::vector<uint32_t>> by_ms;
+        for (size_t i = 0; i < NP; i++) by_ms[sl.pjobs[i].ms].push_back((uint32_t)i);
+        sl.pll_idx.clear();
+        std::vector<std::tuple<unsigned, size_t, size_t>> groups;
+        for (auto &kv : by_ms) { groups.emplace_back(kv.first, sl.pll_idx.size(), kv.second.size()); sl.pll_idx.insert(sl.pll_idx.end(), kv.second.begin(), kv.second.end()); }
+        std::memcpy(sl.hp_pjobs.p, sl.pjobs.data(), NP * sizeof(FxPayJob));
+        std::memcpy(sl.hp_idx.p, sl.blk_job.data(), NB * sizeof(uint32_t));
+        std::memcpy(sl.hp_idx.p + NB, sl.blk_c0.data(), NB * sizeof(uint32_t));
+        std::memcpy(sl.hp_idx.p + 2 * NB, sl.pll_idx.data(), NP * sizeof(uint32_t));
+        // W: payload matched filter (the only payload stage that reads the IQ)
+        HIP_OK(hipMemcpyAsync(sl.d_pjobs.p, sl.hp_pjobs.p, NP * sizeof(FxPayJob), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(sl.d_blk_job.p, sl.hp_idx.p, NB * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(sl.d_blk_c0.p, sl.hp_idx.p + NB, NB * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(sl.d_pll_idx.p, sl.hp_idx.p + 2 * NB, NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipEventRecord(sl.ev_mf0, c->stream));
+        hipLaunchKernelGGL(fx_paymf_kernel, dim3((unsigned)NB), dim3(256), 0, c->stream,
+                           sl.d_pjobs.p, sl.d_blk_job.p, sl.d_blk_c0.p, sl.d_symraw.p, c->d_tables);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipEventRecord(c->ev[3], c->stream));
-        // one PLL grid per modulation scheme present (demodulator resolved at compile time)
-        {
-            std::map<unsigned, std::vector<uint32_t>> by_ms;
-            for (size_t i = 0; i < NP; i++) by_ms[c->pjobs[i].ms].push_back((uint32_t)i);
-            c->pll_idx.clear();
-            std::vector<std::tuple<unsigned, size_t, size_t>> groups;
-            for (auto &kv : by_ms) { groups.emplace_back(kv.first, c->pll_idx.size(), kv.second.size()); c->pll_idx.insert(c->pll_idx.end(), kv.second.begin(), kv.second.end()); }
-            if (c->d_pll_idx.reserve(NP)) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(c->d_pll_idx.p, c->pll_idx.data(), NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-            for (auto &g : groups)
-                HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), c->stream, c->d_pjobs.p, c->d_pll_idx.p + std::get<1>(g),
-                                        c->d_symraw.p, c->d_framesyms.p, c->d_hard.p, c->d_pres.p, c->d_tables));
-        }
-        HIP_OK(hipEventRecord(c->ev[4], c->stream));
-        hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, c->stream,
-                           c->d_pjobs.p, c->d_hard.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_dw.p, c->d_out.p, c->d_pres.p, c->d_tables);
+        HIP_OK(hipEventRecord(sl.ev_mf1, c->stream));
+        // P: payload PLL
+        HIP_OK(hipStreamWaitEvent(c->stream_p, sl.ev_mf1, 0));
+        for (auto &g : groups)
+            HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), c->stream_p, sl.d_pjobs.p, sl.d_pll_idx.p + std::get<1>(g),
+                                    sl.d_symraw.p, sl.d_framesyms.p, sl.d_hard.p, sl.d_pres.p, c->d_tables));
+        HIP_OK(hipEventRecord(sl.ev_pll1, c->stream_p));
+        // D: packet decode, results home
+        HIP_OK(hipStreamWaitEvent(c->stream_d, sl.ev_pll1, 0));
+        hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, c->stream_d,
+                           sl.d_pjobs.p, sl.d_hard.p, c->d_perm.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipEventRecord(c->ev[5], c->stream));
-        HIP_OK(hipMemcpyAsync(c->h_pres.p, c->d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, c->stream));
-        HIP_OK(hipMemcpyAsync(c->h_out.p, c->d_out.p, out_total, hipMemcpyDeviceToHost, c->stream));
+        HIP_OK(hipEventRecord(sl.ev_dec1, c->stream_d));
+        HIP_OK(hipMemcpyAsync(sl.h_pres.p, sl.d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, c->stream_d));
+        HIP_OK(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, out_total, hipMemcpyDeviceToHost, c->stream_d));
         if (c->cfg.want_framesyms) {
-            if (c->h_framesyms.reserve(sym_total)) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(c->h_framesyms.p, c->d_framesyms.p, sym_total * sizeof(float2), hipMemcpyDeviceToHost, c->stream));
+            if (sl.h_framesyms.reserve(sym_total)) return FXRX_ERR_HIP;
+            HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_framesyms.p, sym_total * sizeof(float2), hipMemcpyDeviceToHost, c->stream_d));
         }
-    } else {
-        for (int i = 3; i <= 5; i++) HIP_OK(hipEventRecord(c->ev[i], c->stream));
     }
+    HIP_OK(hipEventRecord(sl.ev_done, NP ? c->stream_d : c->stream));
 
-    // ---- 5. carry the unconsumed tail of every stream into the next call ----
+    // ---- 5. carry the unconsumed tail of every stream into the next call (W, behind the MF) ----
     for (unsigned s = 0; s < NS; s++) {
         StreamState &S = c->st[s]; const Chain &ch = chains[s];
         int64_t keep_from = ch.fresh ? ch.pos : ch.pos - FX_HOP;
@@ -458,35 +523,58 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
         S.cur = nxt; S.carry_len = keep; S.base += keep_from;
         S.pos = ch.pos - keep_from; S.floor_ = ch.floor_ - keep_from; S.fresh = ch.fresh;
     }
-    HIP_OK(hipStreamSynchronize(c->stream));
+    sl.busy = true;
+    c->head = (c->head + 1) % c->depth; c->inflight++;
+    return 0;
+}
 
-    for (auto &o : c->out) {
+int fxrx_collect(fxrx_ctx *c)
+{
+    if (!c) return FXRX_ERR_ARG;
+    if (!c->inflight) { set_err("fxrx_collect: nothing in flight"); return FXRX_ERR_STATE; }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    Slot &sl = *c->slots[c->tail];
+    HIP_OK(hipEventSynchronize(sl.ev_done));
+    HIP_OK(hipStreamSynchronize(c->stream));       // tail-carry copies of this block (cheap; keeps caller buffers reusable)
+    for (auto &o : sl.out) {
         if (o.pjob < 0) continue;
-        const FxPayJob &j = c->pjobs[(size_t)o.pjob]; const FxPayResult &r = c->h_pres.p[o.pjob];
-        o.f.payload = c->h_out.p + j.out_off; o.f.payload_valid = (int)r.payload_valid;
+        const FxPayJob &j = sl.pjobs[(size_t)o.pjob]; const FxPayResult &r = sl.h_pres.p[o.pjob];
+        o.f.payload = sl.h_out.p + j.out_off; o.f.payload_valid = (int)r.payload_valid;
         o.f.evm_sum = r.evm_sum; o.f.evm_db = 10.0f * log10f(r.evm_sum / (float)(j.nsym ? j.nsym : 1));
-        o.f.framesyms = c->cfg.want_framesyms ? (const fx_complex *)(c->h_framesyms.p + j.sym_off) : nullptr;
+        o.f.framesyms = c->cfg.want_framesyms ? (const fx_complex *)(sl.h_framesyms.p + j.sym_off) : nullptr;
     }
-    float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->timing.walk_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->timing.paymf_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[3], c->ev[4]); c->timing.paypll_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[4], c->ev[5]); c->timing.paydec_ms = ms;
-    (void)hipEventElapsedTime(&ms, c->ev[0], c->ev[5]); c->timing.total_ms = ms;
-    return (int)c->out.size();
+    if (!sl.pjobs.empty()) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, sl.ev_mf0, sl.ev_mf1); sl.timing.paymf_ms = ms;
+        (void)hipEventElapsedTime(&ms, sl.ev_mf1, sl.ev_pll1); sl.timing.paypll_ms = ms;     // includes queueing behind earlier blocks when pipelined
+        (void)hipEventElapsedTime(&ms, sl.ev_pll1, sl.ev_dec1); sl.timing.paydec_ms = ms;
+    }
+    sl.timing.total_ms = sl.timing.walk_ms + sl.timing.paymf_ms + sl.timing.paypll_ms + sl.timing.paydec_ms;
+    sl.busy = false; c->last = &sl;
+    c->tail = (c->tail + 1) % c->depth; c->inflight--;
+    return (int)sl.out.size();
+}
+
+int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
+{
+    if (!c) return FXRX_ERR_ARG;
+    while (c->inflight) { int r = fxrx_collect(c); if (r < 0) return r; }      // drain anything a caller left in flight
+    int r = fxrx_submit(c, iq, n_samples, on_device);
+    if (r < 0) return r;
+    return fxrx_collect(c);
 }
 
 // diagnostic: decode-phase shader-clock deltas of payload job i (zeros unless built with -DFX_STAMPS)
 int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8])
 {
-    if (!c || i >= c->pjobs.size()) return FXRX_ERR_ARG;
-    std::memcpy(out, c->h_pres.p[i].stamp, 8 * sizeof(uint32_t)); return 0;
+    if (!c || !c->last || i >= c->last->pjobs.size()) return FXRX_ERR_ARG;
+    std::memcpy(out, c->last->h_pres.p[i].stamp, 8 * sizeof(uint32_t)); return 0;
 }
 
 int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out)
 {
-    if (!c || !out || i >= c->out.size()) return FXRX_ERR_ARG;
-    *out = c->out[i].f; return 0;
+    if (!c || !out || !c->last || i >= c->last->out.size()) return FXRX_ERR_ARG;
+    *out = c->last->out[i].f; return 0;
 }
 
 unsigned int fxrx_gen_frame_len(unsigned int ms, unsigned int check, unsigned int fec0, unsigned int fec1, unsigned int n)

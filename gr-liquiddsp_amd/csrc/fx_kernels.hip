@@ -577,6 +577,9 @@ __global__ __launch_bounds__(PLL_THREADS)
 void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, const float2 *sym_raw, float2 *framesyms,
                       uint8_t *hard, FxPayResult *res, const FxTables *T)
 {
+    // a frame's PLL is one long dependent chain: when it shares a SIMD with walker / decoder waves of other
+    // blocks in flight, let it win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
     __shared__ float2 sc[1024];
     for (int i = threadIdx.x; i < 1024; i += PLL_THREADS) sc[i] = T->sc[i];
     __syncthreads();
@@ -858,6 +861,7 @@ extern "C" __global__ __launch_bounds__(DEC_THREADS)
 void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB,
                       unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
 {
+    __builtin_amdgcn_s_setprio(2);
     FxPayJob job = jobs[blockIdx.x];
     // one wave per frame: pin the loop bounds into SGPRs so that every loop below is scalar-controlled
     job.l0 = __builtin_amdgcn_readfirstlane(job.l0); job.l1 = __builtin_amdgcn_readfirstlane(job.l1);

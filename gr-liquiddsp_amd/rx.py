@@ -63,6 +63,25 @@ class RxContext:
             raise RxError("fxrx_process failed (%d): %s" % (r, self.L.fxrx_last_error().decode()))
         return r
 
+    def set_depth(self, depth):
+        """Allow up to `depth` blocks in flight (submit/collect pipelining over three HIP streams)."""
+        if self.L.fxrx_set_depth(self.h, depth) != 0:
+            raise RxError("fxrx_set_depth failed: %s" % self.L.fxrx_last_error().decode())
+
+    def submit_raw(self, ptrs, counts, on_device):
+        n = self.n_streams
+        a = (C.c_void_p * n)(*ptrs)
+        c = (C.c_uint64 * n)(*counts)
+        r = self.L.fxrx_submit(self.h, a, c, 1 if on_device else 0)
+        if r < 0:
+            raise RxError("fxrx_submit failed (%d): %s" % (r, self.L.fxrx_last_error().decode()))
+
+    def collect_raw(self):
+        r = self.L.fxrx_collect(self.h)
+        if r < 0:
+            raise RxError("fxrx_collect failed (%d): %s" % (r, self.L.fxrx_last_error().decode()))
+        return r
+
     def process(self, streams):
         """streams: list (len n_streams) of numpy complex64 arrays (host) or torch complex64 CUDA tensors."""
         if len(streams) != self.n_streams:

@@ -156,6 +156,19 @@ void      fxrx_reset(fxrx_ctx *c);
  * the buffers they point to stay valid until the next call on this context. */
 int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
 int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out);
+
+/* Pipelined form of fxrx_process (= submit + collect).  fxrx_submit walks the block (it returns once the
+ * frames are located and the payload stages are queued), fxrx_collect waits for the OLDEST submitted block
+ * and exposes its results through fxrx_result / fxrx_last_timing.  With depth d (fxrx_set_depth, 1..8, default
+ * 1) up to d blocks may be in flight: the walk of block n+1, the payload PLL of block n and the packet decode
+ * of block n-1 then overlap on three HIP streams.  Blocks of one stream must still be submitted in order;
+ * device input buffers must stay valid until their block has been collected; results stay valid until the
+ * next fxrx_collect / fxrx_process on the context.  Returns 0 (submit) / result count (collect) or FXRX_ERR_*. */
+int fxrx_set_depth(fxrx_ctx *c, unsigned int depth);
+int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
+int fxrx_collect(fxrx_ctx *c);
+/* diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases of payload job i */
+int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8]);
 /* device-resident payload symbols / hard decisions of the last call (NULL if none) */
 const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n_symbols);
 

@@ -9,7 +9,6 @@ ctx = fx.RxContext(1)
 for it in range(2):
     gf = ctx.process([xd]); ctx.reset()
 L = fx.lib()
-L.fxrx_debug_stamps.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint32 * 8)]
 acc = np.zeros(8)
 n = 0
 for i in range(0, len(gf), 7):
