@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one block in flight (latency mode)")
     ap.add_argument("--depth", type=int, default=4, help="blocks in flight in the timed region")
+    ap.add_argument("--segment", type=int, default=0, help="speculation segment length in samples (0 = library default)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -92,7 +93,7 @@ def main():
     (sid,) = shard_streams(world, rank, world)            # one stream per rank
     x, injected = fx.synth_stream(a.samples, stream_id=sid)
     xd = torch.from_numpy(x).to(dev)
-    ctx = fx.RxContext(1, device=local)
+    ctx = fx.RxContext(1, device=local, segment_len=a.segment)
     torch.cuda.synchronize()
     ptrs, counts = [xd.data_ptr()], [xd.numel()]
 

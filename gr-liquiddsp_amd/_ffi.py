@@ -53,7 +53,8 @@ class Timing(C.Structure):                  # fxrx_timing
     _fields_ = [("walk_ms", C.c_double), ("paymf_ms", C.c_double), ("paypll_ms", C.c_double),
                 ("paydec_ms", C.c_double), ("total_ms", C.c_double),
                 ("hops", C.c_uint64), ("walk_jobs", C.c_uint64), ("repairs", C.c_uint64),
-                ("frames", C.c_uint64), ("payload_symbols", C.c_uint64), ("samples", C.c_uint64), ("hops_cheap", C.c_uint64)]
+                ("frames", C.c_uint64), ("payload_symbols", C.c_uint64), ("samples", C.c_uint64), ("hops_cheap", C.c_uint64),
+                ("host_submit_ms", C.c_double), ("host_walkwait_ms", C.c_double)]
 
 
 # every symbol include/fxrx.h declares (checked by tests/test_cabi.py)

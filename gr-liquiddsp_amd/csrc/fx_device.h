@@ -80,10 +80,11 @@ FX_DEV float atan2c(float y, float x)
     float ax = fabsf(x), ay = fabsf(y);
     float mx = ax > ay ? ax : ay;
     float mn = ax > ay ? ay : ax;
-    if (mx == 0.0f) return 0.0f;
-    float a = mn / mx;
-    float base = 0.0f;
-    if (a > 0.41421356f) { a = (a - 1.0f) / (a + 1.0f); base = 0.78539816f; }
+    const bool big = mn > 0.41421356f * mx;
+    float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    float base = big ? 0.78539816f : 0.0f;
+    float a = num / den;                        // the only division; 0/0 is masked by the last select
     float z = a * a;
     float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
     p = fmaf(p, z, 1.99777106478e-1f);
@@ -91,7 +92,8 @@ FX_DEV float atan2c(float y, float x)
     float r = fmaf(p * z, a, a) + base;
     if (ay > ax) r = 1.57079633f - r;
     if (x < 0.0f) r = 3.14159265f - r;
-    return y < 0.0f ? -r : r;
+    r = y < 0.0f ? -r : r;
+    return mx == 0.0f ? 0.0f : r;
 }
 
 // ---------------------------------------------------------------- 8-point DFT in registers

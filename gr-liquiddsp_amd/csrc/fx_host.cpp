@@ -12,6 +12,7 @@
 // ("repair").  The result is identical to a single sequential walk, for any segment size.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -23,7 +24,7 @@
 
 extern "C" __global__ void fx_walk_kernel(const FxWalkJob *, FxWalkResult *, FxFrame *, const FxTables *);
 extern "C" __global__ void fx_paymf_kernel(const FxPayJob *, const uint32_t *, const uint32_t *, float2 *, const FxTables *);
-extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T);
 extern "C" __global__ void fx_paydec_kernel(const FxPayJob *, const uint8_t *, const uint32_t *, uint8_t *, uint8_t *,
                                             unsigned long long *, uint8_t *, FxPayResult *, const FxTables *);
@@ -97,14 +98,17 @@ struct Slot {
     uint64_t n_syms = 0;
     fxrx_timing timing{};
     hipEvent_t ev_mf0 = nullptr, ev_mf1 = nullptr, ev_pll1 = nullptr, ev_dec1 = nullptr, ev_done = nullptr;
+    hipStream_t stream_p = nullptr, stream_d = nullptr;   // borrowed from the context (see fxrx_ctx_s)
     bool busy = false;
 };
 
 struct fxrx_ctx_s {
     fxrx_config cfg{};
+    // HIP multiplexes streams onto a few hardware queues (a kernel trace of this process shows three usable
+    // ones); streams that share a queue serialise.  So exactly three: W, and two payload streams used
+    // alternately by consecutive blocks, each running its block's PLL -> decode -> result copies in order.
     hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
-    hipStream_t stream_p = nullptr;      // P: payload PLL
-    hipStream_t stream_d = nullptr;      // D: packet decode + result copies
+    hipStream_t stream_p[2] = { nullptr, nullptr };   // A/B: payload PLL + packet decode of even/odd blocks
     hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
@@ -168,7 +172,9 @@ const PlanDev &get_plan(fxrx_ctx_s *c, unsigned n, unsigned check, unsigned fec0
     return c->plans.emplace(k, pd).first->second;
 }
 
-inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)(seg / 512 + 8); }
+// frame-table slots per walk job.  Kept small (the table is copied to the host every block); a segment with
+// more detections than this continues through the FX_EXIT_TABLE_FULL path.
+inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 512 + 8, 24); }
 
 int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
 {
@@ -193,6 +199,7 @@ static int make_slot(fxrx_ctx_s *c)
     std::unique_ptr<Slot> s(new Slot);
     hipEvent_t *ev[5] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll1, &s->ev_dec1, &s->ev_done };
     for (auto e : ev) HIP_OK(hipEventCreate(e));
+    s->stream_p = c->stream_p[c->slots.size() & 1]; s->stream_d = s->stream_p;
     c->slots.push_back(std::move(s));
     return 0;
 }
@@ -208,7 +215,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
-    hipStream_t *ss[3] = { &c->stream, &c->stream_p, &c->stream_d };
+    hipStream_t *ss[3] = { &c->stream, &c->stream_p[0], &c->stream_p[1] };
     for (auto s : ss) if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
     if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
     if (upload_tables(c.get()) != 0) return nullptr;
@@ -220,8 +227,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
 static void sync_all(fxrx_ctx_s *c)
 {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    if (c->stream_p) (void)hipStreamSynchronize(c->stream_p);
-    if (c->stream_d) (void)hipStreamSynchronize(c->stream_d);
+    for (auto s : c->stream_p) if (s) (void)hipStreamSynchronize(s);
 }
 
 void fxrx_destroy(fxrx_ctx *c)
@@ -236,7 +242,7 @@ void fxrx_destroy(fxrx_ctx *c)
     if (c->ev_w0) (void)hipEventDestroy(c->ev_w0);
     if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
     if (c->d_tables) (void)hipFree(c->d_tables);
-    hipStream_t ss[3] = { c->stream, c->stream_p, c->stream_d };
+    hipStream_t ss[3] = { c->stream, c->stream_p[0], c->stream_p[1] };
     for (auto s : ss) if (s) (void)hipStreamDestroy(s);
     delete c;
 }
@@ -278,6 +284,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
     sl.out.clear(); sl.timing = fxrx_timing{};
+    const auto t_enter = std::chrono::steady_clock::now();
 
     // ---- 1. per-stream work buffers: [tail of previous call | new samples] ----
     std::vector<const float2 *> xs(NS); std::vector<int64_t> ns(NS);
@@ -298,7 +305,9 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     uint64_t seg = c->cfg.segment_len;
     if (seg == 0) {
         uint64_t tot = 0; for (unsigned s = 0; s < NS; s++) tot += (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
-        seg = tot / 1024;                                   // aim at ~4 workgroups per CU
+        // ~1.5 walker workgroups per CU: a single wave of workgroups (2 fit per CU) with room left for the
+        // payload kernels of other blocks in flight
+        seg = tot / 384;
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
     }
     seg = std::max<uint64_t>(seg, 4096);
@@ -331,7 +340,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     first_job[NS] = c->jobs.size();
     const size_t NJ = c->jobs.size();
     // one spare job slot + frame region for repairs
-    const uint32_t repair_base = frame_slots; const uint32_t repair_cap = seg_frames_cap(4 * seg);
+    const uint32_t repair_base = frame_slots; const uint32_t repair_cap = 256;
     frame_slots += repair_cap;
     if (c->d_jobs.reserve(NJ + 1) || c->d_res.reserve(NJ + 1) || c->h_res.reserve(NJ + 1) || c->hp_jobs.reserve(NJ + 1) ||
         c->d_frames.reserve(frame_slots) || c->h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
@@ -342,7 +351,11 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     HIP_OK(hipEventRecord(c->ev_w1, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_res.p, c->d_res.p, NJ * sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
     HIP_OK(hipMemcpyAsync(c->h_frames.p, c->d_frames.p, (size_t)repair_base * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipStreamSynchronize(c->stream));
+    {
+        const auto tw = std::chrono::steady_clock::now();
+        HIP_OK(hipStreamSynchronize(c->stream));
+        sl.timing.host_walkwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+    }
     sl.timing.walk_jobs = NJ;
 
     // ---- 3. stitch: per stream, splice speculative lists into the sequential chain ----
@@ -489,25 +502,28 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(sl.ev_mf1, c->stream));
         // P: payload PLL
-        HIP_OK(hipStreamWaitEvent(c->stream_p, sl.ev_mf1, 0));
+        HIP_OK(hipStreamWaitEvent(sl.stream_p, sl.ev_mf1, 0));
+        // stagger concurrent blocks' PLL grids over different CUs (see the kernel): slot k skips k * (grid rounded to 32)
+        const unsigned pll_wgs = (unsigned)((NP + 63) / 64);
+        const unsigned wg_skip = pll_wgs <= 128 ? c->head * ((pll_wgs + 31u) & ~31u) : 0u;
         for (auto &g : groups)
-            HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), c->stream_p, sl.d_pjobs.p, sl.d_pll_idx.p + std::get<1>(g),
+            HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), wg_skip, sl.stream_p, sl.d_pjobs.p, sl.d_pll_idx.p + std::get<1>(g),
                                     sl.d_symraw.p, sl.d_framesyms.p, sl.d_hard.p, sl.d_pres.p, c->d_tables));
-        HIP_OK(hipEventRecord(sl.ev_pll1, c->stream_p));
+        HIP_OK(hipEventRecord(sl.ev_pll1, sl.stream_p));
         // D: packet decode, results home
-        HIP_OK(hipStreamWaitEvent(c->stream_d, sl.ev_pll1, 0));
-        hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, c->stream_d,
+        HIP_OK(hipStreamWaitEvent(sl.stream_d, sl.ev_pll1, 0));
+        hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, sl.stream_d,
                            sl.d_pjobs.p, sl.d_hard.p, c->d_perm.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipEventRecord(sl.ev_dec1, c->stream_d));
-        HIP_OK(hipMemcpyAsync(sl.h_pres.p, sl.d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, c->stream_d));
-        HIP_OK(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, out_total, hipMemcpyDeviceToHost, c->stream_d));
+        HIP_OK(hipEventRecord(sl.ev_dec1, sl.stream_d));
+        HIP_OK(hipMemcpyAsync(sl.h_pres.p, sl.d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, sl.stream_d));
+        HIP_OK(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, out_total, hipMemcpyDeviceToHost, sl.stream_d));
         if (c->cfg.want_framesyms) {
             if (sl.h_framesyms.reserve(sym_total)) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_framesyms.p, sym_total * sizeof(float2), hipMemcpyDeviceToHost, c->stream_d));
+            HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_framesyms.p, sym_total * sizeof(float2), hipMemcpyDeviceToHost, sl.stream_d));
         }
     }
-    HIP_OK(hipEventRecord(sl.ev_done, NP ? c->stream_d : c->stream));
+    HIP_OK(hipEventRecord(sl.ev_done, NP ? sl.stream_d : c->stream));
 
     // ---- 5. carry the unconsumed tail of every stream into the next call (W, behind the MF) ----
     for (unsigned s = 0; s < NS; s++) {
@@ -525,6 +541,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     }
     sl.busy = true;
     c->head = (c->head + 1) % c->depth; c->inflight++;
+    sl.timing.host_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     return 0;
 }
 

@@ -574,16 +574,20 @@ __device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const fl
 
 template <int MS>
 __global__ __launch_bounds__(PLL_THREADS)
-void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, const float2 *sym_raw, float2 *framesyms,
-                      uint8_t *hard, FxPayResult *res, const FxTables *T)
+void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, uint32_t wg_skip, const float2 *sym_raw,
+                      float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
 {
+    // Workgroups are dealt to CUs in launch order from the same starting CU for every grid, so the few waves of
+    // two concurrent PLL grids (consecutive blocks in flight) would pile onto the same SIMDs.  Leading dummy
+    // workgroups shift this grid's real ones onto other CUs.
+    if (blockIdx.x < wg_skip) return;
     // a frame's PLL is one long dependent chain: when it shares a SIMD with walker / decoder waves of other
     // blocks in flight, let it win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
     __shared__ float2 sc[1024];
     for (int i = threadIdx.x; i < 1024; i += PLL_THREADS) sc[i] = T->sc[i];
     __syncthreads();
-    const uint32_t li = blockIdx.x * PLL_THREADS + threadIdx.x;
+    const uint32_t li = (blockIdx.x - wg_skip) * PLL_THREADS + threadIdx.x;
     if (li >= njobs) return;
     const uint32_t f = job_idx[li];
     const FxPayJob job = jobs[f];
@@ -628,11 +632,11 @@ void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
 }
 
 // host-side launcher (lives here so that the template instantiations stay in this translation unit)
-extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
 {
-    const dim3 grid((njobs + PLL_THREADS - 1) / PLL_THREADS), block(PLL_THREADS);
-#define FX_PLL_CASE(M) case M: hipLaunchKernelGGL(fx_paypll_kernel<M>, grid, block, 0, st, jobs, job_idx, njobs, sym_raw, framesyms, hard, res, T); break;
+    const dim3 grid((njobs + PLL_THREADS - 1) / PLL_THREADS + wg_skip), block(PLL_THREADS);
+#define FX_PLL_CASE(M) case M: hipLaunchKernelGGL(fx_paypll_kernel<M>, grid, block, 0, st, jobs, job_idx, njobs, wg_skip, sym_raw, framesyms, hard, res, T); break;
     switch (ms) {
         FX_PLL_CASE(FX_MODEM_PSK2) FX_PLL_CASE(FX_MODEM_PSK4) FX_PLL_CASE(FX_MODEM_PSK8) FX_PLL_CASE(FX_MODEM_PSK16)
         FX_PLL_CASE(FX_MODEM_DPSK2) FX_PLL_CASE(FX_MODEM_DPSK4) FX_PLL_CASE(FX_MODEM_DPSK8) FX_PLL_CASE(FX_MODEM_ASK4)

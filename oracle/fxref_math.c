@@ -61,19 +61,17 @@ void fxr_sincos_u32(uint32_t th, float *c, float *s)
     *s = fmaf(t.im, cd, t.re * sd);
 }
 
-/* atan2 from +,*,/ only (Cephes atanf kernel); returns angle in (-pi, pi] */
+/* atan2 from +,*,/ only (Cephes atanf kernel, one division); returns angle in (-pi, pi] */
 float fxr_atan2(float y, float x)
 {
     float ax = fabsf(x), ay = fabsf(y);
     float mx = ax > ay ? ax : ay;
     float mn = ax > ay ? ay : ax;
-    if (mx == 0.0f) return 0.0f;
-    float a = mn / mx;                          /* in [0,1] */
-    float base = 0.0f;
-    if (a > 0.41421356f) {                      /* tan(pi/8) */
-        a = (a - 1.0f) / (a + 1.0f);
-        base = 0.78539816f;                     /* pi/4 */
-    }
+    int big = mn > 0.41421356f * mx;            /* ratio above tan(pi/8): reduce around pi/4 */
+    float num = big ? mn - mx : mn;
+    float den = big ? mn + mx : mx;
+    float base = big ? 0.78539816f : 0.0f;
+    float a = num / den;
     float z = a * a;
     float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
     p = fmaf(p, z, 1.99777106478e-1f);
@@ -81,7 +79,8 @@ float fxr_atan2(float y, float x)
     float r = fmaf(p * z, a, a) + base;         /* atan(mn/mx) in [0, pi/4] */
     if (ay > ax) r = 1.57079633f - r;
     if (x < 0.0f) r = 3.14159265f - r;
-    return y < 0.0f ? -r : r;
+    r = y < 0.0f ? -r : r;
+    return mx == 0.0f ? 0.0f : r;
 }
 
 float fxr_sum_tree(const float *v, unsigned n)
