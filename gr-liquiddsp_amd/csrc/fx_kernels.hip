@@ -729,7 +729,7 @@ __device__ __forceinline__ void acs_step(uint32_t &P, unsigned code, uint32_t u,
 }
 
 template <bool PUNCT>
-__device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, unsigned long long *dw, int lane, uint32_t *stamp_fwd)
+__device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, unsigned long long *dw, uint8_t *scratch, int lane, uint32_t *stamp_fwd)
 {
 #ifdef FX_STAMPS
     unsigned long long tv0_ = __builtin_readcyclecounter();
@@ -803,54 +803,132 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
 #ifdef FX_STAMPS
     if (lane == 0 && stamp_fwd) *stamp_fwd = (uint32_t)(__builtin_readcyclecounter() - tv0_);
 #endif
-    // traceback from state 0 (wave-uniform, scalar); history words of the next chunk down are prefetched
-    unsigned st = 0;
-    const uint32_t nchunk = (Tn + 63) / 64;
-    unsigned long long w_next = dw[(nchunk - 1) * 64 + lane];
-    for (uint32_t ch = nchunk; ch-- > 0;) {
-        const uint32_t t0 = ch * 64;
-        const uint32_t nstep = min(64u, Tn - t0);
-        const unsigned long long w = w_next;
-        if (ch > 0) w_next = dw[(ch - 1) * 64 + lane];
-        const unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32);
-        unsigned long long bits = 0;                            // bit u = decoded input bit of step t0+u
-        unsigned r = (t0 + nstep) % 6;                          // (t+1) mod 6 for t = t0+nstep-1
+    // ---- traceback, parallel over 64-step chunks with exact verification ----
+    // A serial traceback is Tn dependent steps.  Instead every lane traces whole chunks: chunk c is first entered
+    // from a *guess* S_c of its end state, obtained by tracing chunk c+1 back from state 0 (survivor paths merge
+    // within a few constraint lengths, so the guess is almost always right), and yields the state B_c at its
+    // start.  The chain is then verified: the true end state of chunk c is B_{c+1} (0 for the last chunk); any
+    // chunk whose guess differs is re-traced from the true state, until nothing changes.  At that fixed point
+    // every chunk was entered from the state the serial traceback would have had -- same bits, bit for bit.
+    {
+        const uint32_t nchunk = (Tn + 63) / 64, Lc = nchunk - 1;
+        const uint32_t *dw32 = reinterpret_cast<const uint32_t *>(dw);
+        uint8_t *Sarr = scratch, *Barr = scratch + nchunk;          // per-chunk end-state guess / start state
+        constexpr int NCH = 4;                                      // chains per lane, interleaved to overlap load latency
+        // one pass of up to NCH chunks per lane: st[] in/out, bits out
+        auto trace = [&](const uint32_t (&cidx)[NCH], const bool (&act)[NCH], unsigned (&st)[NCH], uint32_t (&bits)[NCH][2]) {
+            unsigned r[NCH]; uint32_t ns[NCH];
 #pragma unroll
-        for (int h = 1; h >= 0; h--) {
-            const uint32_t ub = 32u * h;
-            if (nstep <= ub) continue;
-            const uint32_t nh = min(nstep - ub, 32u);
-            const unsigned hw = h ? whi : wlo;
-            for (uint32_t uh = nh; uh-- > 0;) {
-                const unsigned ln = ((st >> r) | (st << (6 - r))) & 63u;     // state st of time t+1 lives in lane rotr(st, (t+1) mod 6)
-                const unsigned word = (unsigned)__builtin_amdgcn_readlane((int)hw, (int)ln);
-                bits |= (unsigned long long)(st & 1) << (ub + uh);
-                st = (st >> 1) | (((word >> (nh - 1 - uh)) & 1u) << 5);
-                r = r ? r - 1 : 5;
+            for (int j = 0; j < NCH; j++) {
+                const uint32_t t0 = 64u * cidx[j];
+                ns[j] = act[j] ? min(64u, Tn - t0) : 0u;
+                r[j] = (t0 + ns[j]) % 6u;
+                bits[j][0] = bits[j][1] = 0u;
             }
+#pragma unroll
+            for (int h = 1; h >= 0; h--) {
+                for (int uh = 31; uh >= 0; uh--) {
+                    uint32_t word[NCH]; bool on[NCH];
+#pragma unroll
+                    for (int j = 0; j < NCH; j++) {
+                        on[j] = (uint32_t)(32 * h + uh) < ns[j];
+                        const unsigned ln = ((st[j] >> r[j]) | (st[j] << (6 - r[j]))) & 63u;
+                        word[j] = on[j] ? dw32[((size_t)cidx[j] * 64 + ln) * 2 + h] : 0u;
+                    }
+#pragma unroll
+                    for (int j = 0; j < NCH; j++) {
+                        if (on[j]) {
+                            const uint32_t nh = min(ns[j] - 32u * h, 32u);
+                            bits[j][h] |= (st[j] & 1u) << uh;
+                            st[j] = (st[j] >> 1) | (((word[j] >> (nh - 1 - uh)) & 1u) << 5);
+                            r[j] = r[j] ? r[j] - 1 : 5;
+                        }
+                    }
+                }
+            }
+        };
+        auto emit = [&](uint32_t c, const uint32_t (&b)[2]) {
+            // steps 64c .. 64c+63 are output bytes 8c .. 8c+7, MSB first (the buffer has 8 bytes of slack)
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                lo |= (__brev((b[0] >> (8 * k)) & 0xffu) >> 24) << (8 * k);
+                hi |= (__brev((b[1] >> (8 * k)) & 0xffu) >> 24) << (8 * k);
+            }
+            *reinterpret_cast<uint2 *>(dec + 8 * (size_t)c) = make_uint2(lo, hi);
+        };
+        // pass 1: guess + trace
+        for (uint32_t base = 0; base < nchunk; base += 64 * NCH) {
+            uint32_t cidx[NCH], cnext[NCH], bits[NCH][2]; bool act[NCH], warm[NCH]; unsigned st[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; j++) {
+                cidx[j] = base + 64 * j + lane; act[j] = cidx[j] < nchunk;
+                cnext[j] = cidx[j] + 1; warm[j] = act[j] && cidx[j] < Lc; st[j] = 0;
+            }
+            trace(cnext, warm, st, bits);                               // warm-up through chunk c+1 from state 0
+            unsigned S[NCH];
+#pragma unroll
+            for (int j = 0; j < NCH; j++) S[j] = st[j];
+            trace(cidx, act, st, bits);
+#pragma unroll
+            for (int j = 0; j < NCH; j++) if (act[j]) { Sarr[cidx[j]] = (uint8_t)S[j]; Barr[cidx[j]] = (uint8_t)st[j]; emit(cidx[j], bits[j]); }
         }
-        // steps t0 .. t0+63 are 8 output bytes (t0 is a multiple of 64): lane j<8 packs byte t0/8 + j
-        if (lane < 8) {
-            const uint32_t byte = t0 / 8 + lane;
-            if (byte < n) {
-                unsigned v = 0;
+        // pass 2: verify the chain, re-trace what was entered from a wrong state, repeat to the fixed point
+        for (;;) {
+            __threadfence_block(); __builtin_amdgcn_wave_barrier();
+            bool changed = false;
+            for (uint32_t base = 0; base < nchunk; base += 64 * NCH) {
+                uint32_t cidx[NCH], bits[NCH][2]; bool redo[NCH]; unsigned st[NCH]; bool any = false;
 #pragma unroll
-                for (int k = 0; k < 8; k++) v = (v << 1) | (unsigned)((bits >> (8 * lane + k)) & 1ull);
-                dec[byte] = (uint8_t)v;
+                for (int j = 0; j < NCH; j++) {
+                    cidx[j] = base + 64 * j + lane;
+                    redo[j] = false; st[j] = 0;
+                    if (cidx[j] < nchunk) {
+                        const unsigned need = cidx[j] == Lc ? 0u : Barr[cidx[j] + 1];
+                        if (Sarr[cidx[j]] != need) { redo[j] = true; st[j] = need; any = true; }
+                    }
+                }
+                if (__any(any)) {
+                    unsigned S[NCH];
+#pragma unroll
+                    for (int j = 0; j < NCH; j++) S[j] = st[j];
+                    trace(cidx, redo, st, bits);
+#pragma unroll
+                    for (int j = 0; j < NCH; j++) if (redo[j]) { Sarr[cidx[j]] = (uint8_t)S[j]; Barr[cidx[j]] = (uint8_t)st[j]; emit(cidx[j], bits[j]); }
+                    changed = true;
+                }
             }
+            if (!__any(changed)) break;
         }
     }
 }
 
-__device__ __forceinline__ uint32_t crc_reflected(uint32_t poly_rev, uint32_t mask, const uint8_t *msg, uint32_t n)
+// CRC over n bytes by one wavefront.  The register update is linear over GF(2): every lane runs the bitwise
+// CRC over its own contiguous piece from a zero register (lane 0: from the all-ones preset), and the pieces are
+// combined Horner-style, acc <- M_s acc ^ reg_i, where M_s advances a register through s zero bytes; lane j
+// holds column j of M_s.  Same key as the serial reflected algorithm, ~60x fewer dependent steps.
+__device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, const uint8_t *msg, uint32_t n, int lane)
 {
-    uint32_t key = mask;
-    for (uint32_t i = 0; i < n; i++) {
-        key ^= msg[i];
+    const uint32_t s = n / 64, first = n - 63 * s;            // lane 0 takes the first `first` bytes, the others s each
+    const uint32_t start = lane == 0 ? 0u : first + (uint32_t)(lane - 1) * s, len = lane == 0 ? first : s;
+    uint32_t reg = lane == 0 ? mask : 0u;
+    for (uint32_t i = 0; i < len; i++) {
+        reg ^= msg[start + i];
 #pragma unroll
-        for (int j = 0; j < 8; j++) key = (key >> 1) ^ (poly_rev & (0u - (key & 1u)));
+        for (int j = 0; j < 8; j++) reg = (reg >> 1) ^ (poly_rev & (0u - (reg & 1u)));
     }
-    return (~key) & mask;
+    uint32_t acc = (uint32_t)__builtin_amdgcn_readlane((int)reg, 0);
+    if (s) {
+        uint32_t col = 1u << (lane & 31);
+        for (uint32_t i = 0; i < 8 * s; i++) col = (col >> 1) ^ (poly_rev & (0u - (col & 1u)));
+        for (int i = 1; i < 64; i++) {
+            uint32_t v = (lane < 32 && ((acc >> lane) & 1u)) ? col : 0u;
+#pragma unroll
+            for (int m = 1; m < 32; m <<= 1) v ^= (uint32_t)__shfl_xor((int)v, m, 64);
+            acc = (uint32_t)__builtin_amdgcn_readlane((int)v, 0) ^ (uint32_t)__builtin_amdgcn_readlane((int)reg, i);
+        }
+    }
+    return (~acc) & mask;
 }
 
 #ifdef FX_STAMPS
@@ -895,8 +973,8 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
     FX_STAMP(1);
     uint32_t status = 0;
     const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
-    if (pc1 == 1) viterbi27<false>(1, job.l0, B, A, dw_arena + job.dw_off, lane, nullptr);
-    else if (pc1) viterbi27<true>(pc1, job.l0, B, A, dw_arena + job.dw_off, lane, nullptr);
+    if (pc1 == 1) viterbi27<false>(1, job.l0, B, A, dw_arena + job.dw_off, B, lane, nullptr);
+    else if (pc1) viterbi27<true>(pc1, job.l0, B, A, dw_arena + job.dw_off, B, lane, nullptr);
     else block_fec_decode(job.fec1, job.l0, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(2);
@@ -904,8 +982,8 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
     permute_bits(A, B, perm_arena + job.perm0_off, job.l0, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(3);
-    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, lane, &res[blockIdx.x].stamp[6]);
-    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, lane, &res[blockIdx.x].stamp[6]);
+    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[blockIdx.x].stamp[6]);
+    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[blockIdx.x].stamp[6]);
     else block_fec_decode(job.fec0, job.k, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(4);
@@ -914,20 +992,27 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
     for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     for (uint32_t j = lane; j < job.pay_len; j += DEC_THREADS) out[(size_t)job.out_off + j] = A[j];
-    if (lane == 0) {
+    {
         const uint32_t cl = job.k - job.pay_len;
         uint32_t rx = 0, key = 0;
         for (uint32_t i = 0; i < cl; i++) rx = (rx << 8) | A[job.pay_len + i];
         switch (job.check) {
-        case FX_CRC_CHECKSUM: { uint32_t s = 0; for (uint32_t i = 0; i < job.pay_len; i++) s += A[i]; key = (~s + 1u) & 0xff; break; }
-        case FX_CRC_8:  key = crc_reflected(0xE0u, 0xFFu, A, job.pay_len); break;
-        case FX_CRC_16: key = crc_reflected(0xA001u, 0xFFFFu, A, job.pay_len); break;
-        case FX_CRC_24: key = crc_reflected(0xD3B6BAu, 0xFFFFFFu, A, job.pay_len); break;
-        case FX_CRC_32: key = crc_reflected(0xEDB88320u, 0xFFFFFFFFu, A, job.pay_len); break;
+        case FX_CRC_CHECKSUM: {
+            uint32_t sm = 0;
+            for (uint32_t i = lane; i < job.pay_len; i += DEC_THREADS) sm += A[i];
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) sm += (uint32_t)__shfl_xor((int)sm, m, 64);
+            key = (~sm + 1u) & 0xff; break; }
+        case FX_CRC_8:  key = crc_wave(0xE0u, 0xFFu, A, job.pay_len, lane); break;
+        case FX_CRC_16: key = crc_wave(0xA001u, 0xFFFFu, A, job.pay_len, lane); break;
+        case FX_CRC_24: key = crc_wave(0xD3B6BAu, 0xFFFFFFu, A, job.pay_len, lane); break;
+        case FX_CRC_32: key = crc_wave(0xEDB88320u, 0xFFFFFFFFu, A, job.pay_len, lane); break;
         default: key = 0; break;
         }
-        res[blockIdx.x].payload_valid = (key == rx) ? 1u : 0u;
-        res[blockIdx.x].status = status;
+        if (lane == 0) {
+            res[blockIdx.x].payload_valid = (key == rx) ? 1u : 0u;
+            res[blockIdx.x].status = status;
+        }
     }
     FX_STAMP(5);
 }
