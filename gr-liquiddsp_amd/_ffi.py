@@ -68,7 +68,7 @@ EXPORTS = [
     "flexframegenprops_init_default", "flexframegen_create", "flexframegen_destroy", "flexframegen_setprops",
     "flexframegen_assemble", "flexframegen_getframelen", "flexframegen_write_samples", "fxrx_gen_set_delay",
     "fxrx_last_error", "fxrx_version", "fxrx_device_count", "fxrx_create", "fxrx_destroy", "fxrx_reset",
-    "fxrx_process", "fxrx_result", "fxrx_set_depth", "fxrx_submit", "fxrx_collect", "fxrx_debug_stamps", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
+    "fxrx_process", "fxrx_result", "fxrx_set_depth", "fxrx_submit", "fxrx_collect", "fxrx_debug_stamps", "fxrx_debug_walk_stamps", "fxrx_debug_walk_maxjob", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
     "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
     "fxrx_outer_from_index", "fxrx_outer_to_index",
 ]

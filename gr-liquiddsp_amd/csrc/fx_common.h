@@ -94,6 +94,7 @@ struct FxWalkResult {
     uint32_t has_handoff;   // hand-off target valid
     int64_t  handoff_start; int32_t handoff_offset; uint32_t hops;
     float    handoff_rxy; uint32_t hops_cheap;
+    uint32_t stamp[4];      // diagnostic builds: shader clocks in coarse scan / exact seek / align / header
 };
 
 // ---- payload stage records ----

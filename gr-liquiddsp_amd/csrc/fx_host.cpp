@@ -121,6 +121,8 @@ struct fxrx_ctx_s {
     // pipeline
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
     Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
+    uint64_t walk_stamp[4] = { 0, 0, 0, 0 };   // diagnostic builds: summed walker phase clocks of the last submit
+    uint64_t walk_stamp_max = 0, walk_stamp_maxjob[4] = { 0, 0, 0, 0 }, walk_maxjob_hops = 0, walk_maxjob_cheap = 0, walk_maxjob_frames = 0;
 };
 
 namespace {
@@ -284,6 +286,8 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
     sl.out.clear(); sl.timing = fxrx_timing{};
+    for (auto &w : c->walk_stamp) w = 0;
+    c->walk_stamp_max = 0;
     const auto t_enter = std::chrono::steady_clock::now();
 
     // ---- 1. per-stream work buffers: [tail of previous call | new samples] ----
@@ -382,6 +386,8 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         };
         for (;;) {
             sl.timing.hops += R.hops; sl.timing.hops_cheap += R.hops_cheap;
+            for (int i = 0; i < 4; i++) c->walk_stamp[i] += R.stamp[i];
+            { uint64_t tot = (uint64_t)R.stamp[0] + R.stamp[1] + R.stamp[2] + R.stamp[3]; if (tot > c->walk_stamp_max) { c->walk_stamp_max = tot; for (int i = 0; i < 4; i++) c->walk_stamp_maxjob[i] = R.stamp[i]; c->walk_maxjob_hops = R.hops; c->walk_maxjob_cheap = R.hops_cheap; c->walk_maxjob_frames = R.n_frames; } }
             uint32_t nf = R.n_frames;
             if (R.exit_code == FX_EXIT_PAYLOAD && nf > 0) nf--;            // incomplete frame: redo next call
             for (uint32_t i = m; i < nf; i++) {
@@ -580,6 +586,9 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
     if (r < 0) return r;
     return fxrx_collect(c);
 }
+
+int fxrx_debug_walk_stamps(const fxrx_ctx *c, uint64_t out[4]) { if (!c) return FXRX_ERR_ARG; std::memcpy(out, c->walk_stamp, sizeof c->walk_stamp); return 0; }
+int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]) { if (!c) return FXRX_ERR_ARG; for (int i = 0; i < 4; i++) out[i] = c->walk_stamp_maxjob[i]; out[4] = c->walk_maxjob_hops; out[5] = c->walk_maxjob_cheap; out[6] = c->walk_maxjob_frames; out[7] = c->walk_stamp_max; return 0; }
 
 // diagnostic: decode-phase shader-clock deltas of payload job i (zeros unless built with -DFX_STAMPS)
 int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8])

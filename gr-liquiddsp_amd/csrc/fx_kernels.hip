@@ -33,6 +33,7 @@ struct WalkLds {
     float2 P[256];                  // x conj(s) products (ALIGN)
     float  m2[FX_NFFT];
     float2 hdr[FX_HDR_SYM];
+    float2 cw[5 * FX_HOP + 8];      // coarse pre-lock scan: overlap half + four new hops
     float2 pb[16];                  // de-rotated pilots
     float  taps[FX_MF_TAPS];
     float  redf[WALK_WAVES]; float2 redc[WALK_WAVES];
@@ -68,42 +69,58 @@ __device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_,
     return (p >= floor_ && p >= 0 && p < n) ? x[p] : make_float2(0.0f, 0.0f);
 }
 
-// header: 54 received bytes -> 20 header bytes + CRC verdict.  Single thread, ~2k integer ops.
-__device__ int decode_header_bytes(WalkLds &L, const FxTables *T, uint8_t *out)
+// header: 54 received bytes (L.b0) -> 20 header bytes (L.b1[0..19]) + CRC verdict (L.u[1]).
+// Called by the whole workgroup; every stage is spread over threads (a one-thread version of this cost more
+// than the rest of the header span together).
+__device__ __forceinline__ void decode_header_bytes(WalkLds &L, const FxTables *T, int tid)
 {
     uint8_t *b0 = L.b0, *b1 = L.b1;
-    for (int j = 0; j < FX_HDR_ENC; j++) b1[j] = 0;
-    for (int i = 0; i < FX_HDR_ENC * 8; i++) {           // de-interleave (54)
-        unsigned s = T->perm54[i];
-        if ((b0[s >> 3] >> (7 - (s & 7))) & 1) b1[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
+    auto gather_byte = [&](const uint8_t *src, const uint16_t *perm, int j) -> uint8_t {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) { const unsigned s_ = perm[8 * j + b]; v = (v << 1) | ((src[s_ >> 3] >> (7 - (s_ & 7))) & 1u); }
+        return (uint8_t)v;
+    };
+    if (tid < FX_HDR_ENC) b1[tid] = gather_byte(b0, T->perm54, tid);                       // de-interleave (54)
+    __syncthreads();
+    if (tid < FX_HDR_E0) b0[tid] = (uint8_t)((T->h84dec[b1[2 * tid]] << 4) | T->h84dec[b1[2 * tid + 1]]);   // Hamming(8,4)
+    __syncthreads();
+    if (tid < FX_HDR_E0) b1[tid] = gather_byte(b0, T->perm27, tid);                        // de-interleave (27)
+    __syncthreads();
+    if (tid < 192) {                                                                       // SECDED(72,64): 3 blocks x 64 bits
+        const int blk = tid >> 6, j = tid & 63;
+        const uint8_t *e = b1 + 9 * blk;
+        const unsigned bit = (e[1 + (j >> 3)] >> (7 - (j & 7))) & 1u;
+        unsigned par = bit ? T->sdcol[j] : 0u;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) par ^= (unsigned)__shfl_xor((int)par, m, 64);
+        const unsigned syn = (e[0] ^ par) & 0xffu;
+        // single data-bit error: the (unique) lane whose column equals the syndrome flips its bit
+        const bool fix = syn != 0 && __popc(syn) != 1 && T->sdcol[j] == syn;
+        const unsigned long long word = __ballot(bit ^ (fix ? 1u : 0u));                   // corrected 64 data bits, bit j = lane j
+        if (j < 8) {
+            unsigned v = 0;
+#pragma unroll
+            for (int b = 0; b < 8; b++) v = (v << 1) | (unsigned)((word >> (8 * j + b)) & 1ull);
+            b0[8 * blk + j] = (uint8_t)v;
+        }
     }
-    for (int j = 0; j < FX_HDR_E0; j++)                  // Hamming(8,4)
-        b0[j] = (uint8_t)((T->h84dec[b1[2 * j]] << 4) | T->h84dec[b1[2 * j + 1]]);
-    for (int j = 0; j < FX_HDR_E0; j++) b1[j] = 0;
-    for (int i = 0; i < FX_HDR_E0 * 8; i++) {            // de-interleave (27)
-        unsigned s = T->perm27[i];
-        if ((b0[s >> 3] >> (7 - (s & 7))) & 1) b1[i >> 3] |= (uint8_t)(0x80u >> (i & 7));
+    __syncthreads();
+    if (tid < FX_HDR_CRC) { const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 }; b0[tid] ^= mask[tid & 3]; }   // de-whiten
+    __syncthreads();
+    if (tid < FX_HDR_DEC) b1[tid] = b0[tid];
+    if (tid == 0) {
+        uint32_t key = 0xFFFFFFFFu;
+        for (int j = 0; j < FX_HDR_DEC; j++) {
+            key ^= b0[j];
+#pragma unroll
+            for (int b = 0; b < 8; b++) key = (key >> 1) ^ (0xEDB88320u & (0u - (key & 1u)));
+        }
+        key = ~key;
+        const uint32_t rx = ((uint32_t)b0[20] << 24) | ((uint32_t)b0[21] << 16) | ((uint32_t)b0[22] << 8) | b0[23];
+        L.u[1] = key == rx;
     }
-    for (int blk = 0; blk < 3; blk++) {                  // SECDED(72,64)
-        const uint8_t *e = b1 + 9 * blk; uint8_t *d = b0 + 8 * blk;
-        uint8_t par = 0;
-        for (int j = 0; j < 8; j++) d[j] = e[1 + j];
-        for (int j = 0; j < 64; j++) if (d[j >> 3] & (0x80u >> (j & 7))) par ^= T->sdcol[j];
-        uint8_t syn = (uint8_t)(e[0] ^ par);
-        if (syn != 0 && __popc((unsigned)syn) != 1)
-            for (int j = 0; j < 64; j++) if (T->sdcol[j] == syn) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); break; }
-    }
-    const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
-    for (int j = 0; j < FX_HDR_CRC; j++) b0[j] ^= mask[j & 3];
-    uint32_t key = 0xFFFFFFFFu;
-    for (int j = 0; j < FX_HDR_DEC; j++) {
-        key ^= b0[j];
-        for (int b = 0; b < 8; b++) key = (key >> 1) ^ (0xEDB88320u & (0u - (key & 1u)));
-    }
-    key = ~key;
-    uint32_t rx = ((uint32_t)b0[20] << 24) | ((uint32_t)b0[21] << 16) | ((uint32_t)b0[22] << 8) | b0[23];
-    for (int j = 0; j < FX_HDR_DEC; j++) out[j] = b0[j];
-    return key == rx;
+    __syncthreads();
 }
 
 extern "C" __global__ __launch_bounds__(WALK_THREADS, 2)
@@ -125,6 +142,12 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     uint32_t nfr = 0, hops = 0, hops_cheap = 0, exact_left = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
     int64_t ho_start = 0; int32_t ho_off = 0; float ho_rxy = 0.0f;
     float x2_0 = 0.0f;
+#ifdef FX_STAMPS
+    unsigned long long wt_ = __builtin_readcyclecounter(); uint32_t wst_[4] = { 0, 0, 0, 0 };
+#define WSTAMP(i) do { unsigned long long t2_ = __builtin_readcyclecounter(); wst_[i] += (uint32_t)(t2_ - wt_); wt_ = t2_; } while (0)
+#else
+#define WSTAMP(i) do { } while (0)
+#endif
     const float s2sum = T->s2sum;
     const float2 *sc = T->sc;
 
@@ -138,6 +161,64 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             if (job.handoff && locked) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }
         }
         if (pos + FX_HOP > n) { exit_code = FX_EXIT_NEED_DATA; break; }
+
+        // ------------------------------------------------------------ pre-lock coarse scan, four hops at a time
+        // (same differential correlator as the single-hop form below, one window per wave, no block barriers
+        // inside; used while at least four hops remain before the segment end / end of data)
+        if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0 && pos + 4 * FX_HOP <= n && pos + 3 * FX_HOP < job.stop) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 5; q++) L.cw[q * FX_HOP + tid] = xv(x, pos - FX_HOP + q * FX_HOP + tid, floor_, n);
+            __syncthreads();
+            hops_cheap += 4;
+            {
+                const float2 *w = L.cw + FX_HOP * wave;               // this wave's 512-sample window
+                float2 a[8]; float e = 0.0f; float2 sm = make_float2(0.0f, 0.0f);
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * q;
+                    a[q] = (i < FX_NFFT - 1) ? cmulc(w[i + 1], w[i]) : make_float2(0.0f, 0.0f);
+                    e += cm2(a[q]); sm = cadd(sm, a[q]);
+                }
+                e = wave_sum(e); sm.x = wave_sum(sm.x); sm.y = wave_sum(sm.y);
+                e -= cm2(sm) * (1.0f / (float)FX_NFFT);
+                fft512_wave(a, L.scr[wave], lane, twA, twB);
+                const int kb = (lane >> 3) + 8 * (lane & 7);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int t = 0; t < 8; t++) { float2 y = cmulc(a[t], T->TD[kb + 64 * t]); L.scr[wave][kb + 64 * t] = make_float2(y.y, y.x); }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = L.scr[wave][lane + 64 * q];
+                __builtin_amdgcn_wave_barrier();
+                fft512_wave(a, L.scr[wave], lane, twA, twB);
+                float bv = -1.0f; uint32_t bk = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    const uint32_t k = (uint32_t)kb + 64 * t;
+                    const float m = cm2(a[t]);
+                    if (k < FX_NFFT - FX_S_LEN && m > bv) { bv = m; bk = k; }
+                }
+                wave_argmax(bv, bk);
+                const bool hit = e > 0.0f && bv > 0.06f * e * T->td2sum * (float)FX_NFFT * (float)FX_NFFT;
+                if (lane == 0) L.u[9 + wave] = hit ? bk : 0xFFFFFFFFu;
+            }
+            __syncthreads();
+            int hw = -1;
+#pragma unroll
+            for (int w = WALK_WAVES - 1; w >= 0; w--) if (L.u[9 + w] != 0xFFFFFFFFu) hw = w;
+            if (hw >= 0) {
+                const int64_t p = pos - FX_HOP + (int64_t)FX_HOP * hw + (int64_t)L.u[9 + hw];
+                pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
+                L.win[tid] = make_float2(0.0f, 0.0f);
+            } else {
+                L.win[tid] = L.cw[4 * FX_HOP + tid];                  // last hop becomes the overlap half
+                pos += 4 * FX_HOP; fresh = false;
+            }
+            __syncthreads();
+            WSTAMP(0);
+            continue;
+        }
 
         float2 nw = xv(x, pos + tid, floor_, n);
         L.win[FX_HOP + tid] = nw;
@@ -247,6 +328,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             bidx = bk & (FX_NFFT - 1); boff = (int)(bk >> 9) - FX_RANGE;
             det = (peak > job.threshold) && (bidx < FX_NFFT - FX_S_LEN);
         }
+        WSTAMP(1);
         if (!det) {                                                    // slide the window by one hop
             __syncthreads();
             L.win[tid] = nw;
@@ -340,6 +422,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             phi = atan2c(metric.y, metric.x);
         }
 
+        WSTAMP(2);
         FxFrame fr;
         fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
         fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
@@ -439,9 +522,10 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         if (tid < FX_HDR_ENC)
             L.b0[tid] = (uint8_t)((L.hs[4 * tid] << 6) | (L.hs[4 * tid + 1] << 4) | (L.hs[4 * tid + 2] << 2) | L.hs[4 * tid + 3]);
         __syncthreads();
+        decode_header_bytes(L, T, tid);
         if (tid == 0) {
-            uint8_t hd[FX_HDR_DEC];
-            int ok = decode_header_bytes(L, T, hd);
+            const uint8_t *hd = L.b1;
+            int ok = (int)L.u[1];
             unsigned pay_len = 0, ms = 0, check = 0, fec0 = 0, fec1 = 0, nsym = 0;
             if (ok) {
                 const uint8_t *h = hd + FX_HDR_USER;
@@ -455,7 +539,6 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
                     nsym = (bits + bps - 1) / bps;
                 }
             }
-            for (int j = 0; j < FX_HDR_DEC; j++) L.b1[j] = hd[j];
             L.u[1] = (uint32_t)ok; L.u[2] = pay_len; L.u[3] = ms; L.u[4] = check; L.u[5] = fec0; L.u[6] = fec1; L.u[7] = nsym;
         }
         __syncthreads();
@@ -471,6 +554,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             last_c += fr.pay_sym_len;
         }
         fr.next = a0 + sym_sample(last_c, fr.mfc0) + 1;
+        WSTAMP(3);
         if (!locked && !hv) {
             // speculative walker, header did not check out: most likely a false alarm on payload data.
             // Do not skip the 618 samples a real invalid frame would consume (a true preamble may sit
@@ -501,6 +585,11 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
         r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
         r.handoff_rxy = ho_rxy; r.hops_cheap = hops_cheap;
+#ifdef FX_STAMPS
+        for (int i = 0; i < 4; i++) r.stamp[i] = wst_[i];
+#else
+        for (int i = 0; i < 4; i++) r.stamp[i] = 0;
+#endif
         results[blockIdx.x] = r;
     }
 }
