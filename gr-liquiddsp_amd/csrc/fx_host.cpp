@@ -108,7 +108,8 @@ struct fxrx_ctx_s {
     // ones); streams that share a queue serialise.  So exactly three: W, and two payload streams used
     // alternately by consecutive blocks, each running its block's PLL -> decode -> result copies in order.
     hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
-    hipStream_t stream_p[2] = { nullptr, nullptr };   // A/B: payload PLL + packet decode of even/odd blocks
+    hipStream_t stream_p[4] = { nullptr, nullptr, nullptr, nullptr };   // payload PLL + packet decode, blocks round-robin
+    unsigned n_pstreams = 2;
     hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
@@ -201,7 +202,7 @@ static int make_slot(fxrx_ctx_s *c)
     std::unique_ptr<Slot> s(new Slot);
     hipEvent_t *ev[5] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll1, &s->ev_dec1, &s->ev_done };
     for (auto e : ev) HIP_OK(hipEventCreate(e));
-    s->stream_p = c->stream_p[c->slots.size() & 1]; s->stream_d = s->stream_p;
+    s->stream_p = c->stream_p[c->slots.size() % c->n_pstreams]; s->stream_d = s->stream_p;
     c->slots.push_back(std::move(s));
     return 0;
 }
@@ -217,8 +218,10 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
-    hipStream_t *ss[3] = { &c->stream, &c->stream_p[0], &c->stream_p[1] };
-    for (auto s : ss) if (hipStreamCreateWithFlags(s, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(4, std::max(1, std::atoi(e)));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+    for (unsigned i = 0; i < c->n_pstreams; i++)
+        if (hipStreamCreateWithFlags(&c->stream_p[i], hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
     if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
     if (upload_tables(c.get()) != 0) return nullptr;
     c->st.resize(cfg->n_streams);
@@ -244,8 +247,8 @@ void fxrx_destroy(fxrx_ctx *c)
     if (c->ev_w0) (void)hipEventDestroy(c->ev_w0);
     if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
     if (c->d_tables) (void)hipFree(c->d_tables);
-    hipStream_t ss[3] = { c->stream, c->stream_p[0], c->stream_p[1] };
-    for (auto s : ss) if (s) (void)hipStreamDestroy(s);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (auto s : c->stream_p) if (s) (void)hipStreamDestroy(s);
     delete c;
 }
 

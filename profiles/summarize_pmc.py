@@ -1,0 +1,35 @@
+"""Turns the two rocprofv3 --pmc runs of profiles/collect_pmc.sh into profiles/r01_pmc_traffic.json.
+
+Units / corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZE are in KiB-ish units of 1024 B as
+reported by rocprofv3 (value * 1024 = bytes); on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
+streams, i.e. reads half the bytes -> corrected fetch = 2 x raw.  WRITE_SIZE is taken as is.  Access patterns other
+than 16-B-per-lane streams are uncalibrated; both raw and corrected figures are kept."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
+
+
+def load(sub, counter):
+    acc = defaultdict(list)
+    for f in glob.glob(os.path.join(root, sub, "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r.get("Counter_Name") == counter:
+                name = r["Kernel_Name"]
+                name = "fx_paypll_kernel" if "paypll" in name else name
+                acc[name].append(float(r["Counter_Value"]))
+    return acc
+
+
+fetch, write = load("pmc_fetch", "FETCH_SIZE"), load("pmc_write", "WRITE_SIZE")
+out = {"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, bench.py --no-pipeline (20 Msample stream)",
+       "unit_note": "counter value x 1024 = bytes; FETCH_SIZE x2 on gfx950 (see docstring)", "kernels": {}}
+for k in sorted(set(fetch) | set(write)):
+    if not k.startswith("fx_"):
+        continue
+    f = sum(fetch.get(k, [0])) / max(len(fetch.get(k, [0])), 1) * 1024.0
+    w = sum(write.get(k, [0])) / max(len(write.get(k, [0])), 1) * 1024.0
+    out["kernels"][k] = {"launches_sampled": len(fetch.get(k, [])), "fetch_bytes_raw": f, "write_bytes": w,
+                         "hbm_bytes_per_launch_raw": f + w, "hbm_bytes_per_launch_corrected": 2 * f + w}
+json.dump(out, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+print(json.dumps(out, indent=1))
