@@ -182,8 +182,55 @@ struct Interleaver {
 // ------------------------------------------------------------------ block codes
 struct BlockCodes {
     uint8_t h84_enc[16], h84_dec[256], sd_col[64];
+    uint8_t sd22_col[16], sd39_col[32];
+    uint8_t h74_enc[16], h74_dec[128]; uint16_t h128_enc[256]; uint8_t h128_dec[4096];
+    uint32_t gol_enc[4096], gol_err[4096];
+    unsigned gol_syndrome(uint32_t cw) const { return (unsigned)((gol_enc[(cw >> 12) & 0xfff] ^ cw) & 0xfff); }
     BlockCodes()
     {
+        {   // Hsiao columns for the two short SECDED codes: the first 16 / 32 weight-3 words of 6 / 7 bits
+            unsigned k = 0;
+            for (unsigned v = 1; v < 64 && k < 16; v++) if (__builtin_popcount(v) == 3) sd22_col[k++] = (uint8_t)v;
+            k = 0;
+            for (unsigned v = 1; v < 128 && k < 32; v++) if (__builtin_popcount(v) == 3) sd39_col[k++] = (uint8_t)v;
+        }
+        for (unsigned d = 0; d < 16; d++) {     // Hamming(7,4), systematic
+            unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
+            h74_enc[d] = (uint8_t)((d << 3) | ((d1 ^ d2 ^ d3) << 2) | ((d0 ^ d2 ^ d3) << 1) | (d0 ^ d1 ^ d3));
+        }
+        for (unsigned r = 0; r < 128; r++) {
+            unsigned best = 0, bd = 99;
+            for (unsigned d = 0; d < 16; d++) { unsigned w = (unsigned)__builtin_popcount(r ^ h74_enc[d]); if (w < bd) { bd = w; best = d; } }
+            h74_dec[r] = (uint8_t)best;
+        }
+        for (unsigned d = 0; d < 256; d++) {    // Hamming(12,8), parity at positions 1,2,4,8 (1-based, MSB first)
+            static const unsigned pos[8] = { 3, 5, 6, 7, 9, 10, 11, 12 };
+            unsigned cw = 0;
+            for (unsigned i = 0; i < 8; i++) if (d & (0x80u >> i)) cw |= 1u << (12 - pos[i]);
+            for (unsigned pb = 1; pb <= 8; pb <<= 1) {
+                unsigned par = 0;
+                for (unsigned q = 1; q <= 12; q++) if ((q & pb) && (cw & (1u << (12 - q)))) par ^= 1;
+                if (par) cw |= 1u << (12 - pb);
+            }
+            h128_enc[d] = (uint16_t)cw;
+        }
+        for (unsigned r = 0; r < 4096; r++) {
+            unsigned best = 0, bd = 99;
+            for (unsigned d = 0; d < 256; d++) { unsigned w = (unsigned)__builtin_popcount(r ^ h128_enc[d]); if (w < bd) { bd = w; best = d; } }
+            h128_dec[r] = (uint8_t)best;
+        }
+        for (unsigned d = 0; d < 4096; d++) {   // extended Golay(24,12): cyclic (23,12) with g = 0xC75, plus overall parity
+            uint32_t reg = d << 11;
+            for (int i = 22; i >= 11; i--) if (reg & (1u << i)) reg ^= 0xC75u << (i - 11);
+            uint32_t cw23 = (d << 11) | (reg & 0x7ff);
+            gol_enc[d] = (cw23 << 1) | ((uint32_t)__builtin_popcount(cw23) & 1u);
+        }
+        for (auto &e : gol_err) e = 0xFFFFFFFFu;
+        gol_err[0] = 0;
+        auto note = [&](uint32_t e) { unsigned sy = gol_syndrome(e); if (gol_err[sy] == 0xFFFFFFFFu) gol_err[sy] = e; };
+        for (int a = 0; a < 24; a++) note(1u << a);
+        for (int a = 0; a < 24; a++) for (int b = a + 1; b < 24; b++) note((1u << a) | (1u << b));
+        for (int a = 0; a < 24; a++) for (int b = a + 1; b < 24; b++) for (int c2 = b + 1; c2 < 24; c2++) note((1u << a) | (1u << b) | (1u << c2));
         for (unsigned d = 0; d < 16; d++) {
             unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
             unsigned c = (d << 4) | ((d1 ^ d2 ^ d3) << 3) | ((d0 ^ d2 ^ d3) << 2) | ((d0 ^ d1 ^ d3) << 1);
@@ -224,11 +271,29 @@ inline void conv_masks(int p, unsigned &pa, unsigned &pb)
     default: pa = 1; pb = 1; break;
     }
 }
-inline bool fec_supported(unsigned fs) { return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || conv_period(fs) != 0; }
+inline bool blk_spec(unsigned fs, unsigned &k, unsigned &n)
+{
+    switch (fs) {
+    case FX_FEC_HAMMING74: k = 4; n = 7; return true;
+    case FX_FEC_HAMMING128: k = 8; n = 12; return true;
+    case FX_FEC_GOLAY2412: k = 12; n = 24; return true;
+    default: return false;
+    }
+}
+inline bool fec_supported(unsigned fs)
+{
+    unsigned k, n;
+    return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || fs == FX_FEC_SECDED2216 ||
+           fs == FX_FEC_SECDED3932 || blk_spec(fs, k, n) || conv_period(fs) != 0;
+}
 inline unsigned fec_enc_len(unsigned fs, unsigned n)
 {
     int p = conv_period(fs);
     if (p) { unsigned T = 8 * n + 6; unsigned bits = p == 1 ? 2 * T : T + (T + (unsigned)p - 1) / (unsigned)p; return (bits + 7) / 8; }
+    unsigned bk, bn;
+    if (blk_spec(fs, bk, bn)) { unsigned nb = (8 * n + bk - 1) / bk; return (nb * bn + 7) / 8; }
+    if (fs == FX_FEC_SECDED2216) return 3 * (n / 2) + ((n % 2) ? (n % 2) + 1 : 0);
+    if (fs == FX_FEC_SECDED3932) return 5 * (n / 4) + ((n % 4) ? (n % 4) + 1 : 0);
     if (fs == FX_FEC_HAMMING84) return 2 * n;
     if (fs == FX_FEC_SECDED7264) return 9 * (n / 8) + ((n % 8) ? (n % 8) + 1 : 0);
     return n;
@@ -248,6 +313,26 @@ inline void fec_encode(unsigned fs, unsigned n, const uint8_t *dec, uint8_t *enc
             if ((pa >> col) & 1) { if (__builtin_popcount(sr & 0x6d) & 1) enc[nb >> 3] |= (uint8_t)(0x80u >> (nb & 7)); nb++; }
             if ((pb >> col) & 1) { if (__builtin_popcount(sr & 0x4f) & 1) enc[nb >> 3] |= (uint8_t)(0x80u >> (nb & 7)); nb++; }
         }
+        return;
+    }
+    unsigned bk, bn;
+    if (blk_spec(fs, bk, bn)) {      // bit-packed block codes: k-bit blocks MSB first -> n-bit codewords back to back
+        const unsigned nb = (8 * n + bk - 1) / bk, el = fec_enc_len(fs, n);
+        std::memset(enc, 0, el);
+        for (unsigned j = 0; j < nb; j++) {
+            unsigned d = 0;
+            for (unsigned i = 0; i < bk; i++) { unsigned q = j * bk + i; d = (d << 1) | (q < 8 * n ? (dec[q >> 3] >> (7 - (q & 7))) & 1u : 0u); }
+            const uint32_t cw = fs == FX_FEC_HAMMING74 ? bc.h74_enc[d] : fs == FX_FEC_HAMMING128 ? bc.h128_enc[d] : bc.gol_enc[d];
+            for (unsigned i = 0; i < bn; i++) { unsigned q = j * bn + i; if ((cw >> (bn - 1 - i)) & 1u) enc[q >> 3] |= (uint8_t)(0x80u >> (q & 7)); }
+        }
+        return;
+    }
+    if (fs == FX_FEC_SECDED2216 || fs == FX_FEC_SECDED3932) {
+        const unsigned nd = fs == FX_FEC_SECDED2216 ? 2 : 4; const uint8_t *col = fs == FX_FEC_SECDED2216 ? bc.sd22_col : bc.sd39_col;
+        auto par = [&](const uint8_t *d) { uint8_t pp = 0; for (unsigned j = 0; j < 8 * nd; j++) if (d[j >> 3] & (0x80u >> (j & 7))) pp ^= col[j]; return pp; };
+        unsigned i = 0, j = 0;
+        for (; i + nd <= n; i += nd, j += nd + 1) { enc[j] = par(dec + i); std::memcpy(enc + j + 1, dec + i, nd); }
+        if (n % nd) { uint8_t d[8] = { 0 }; std::memcpy(d, dec + i, n % nd); enc[j] = par(d); std::memcpy(enc + j + 1, d, n % nd); }
         return;
     }
     if (fs == FX_FEC_HAMMING84) { for (unsigned i = 0; i < n; i++) { enc[2 * i] = bc.h84_enc[dec[i] >> 4]; enc[2 * i + 1] = bc.h84_enc[dec[i] & 15]; } return; }

@@ -23,6 +23,10 @@ struct FxTables {
     uint16_t perm27[FX_HDR_E0 * 8];
     uint8_t  h84dec[256];
     uint8_t  sdcol[64];
+    uint8_t  sd22col[16], sd39col[32];
+    uint8_t  h74dec[128];
+    uint8_t  h128dec[4096];
+    uint32_t golenc[4096], golerr[4096];   // Golay(24,12): codeword of a 12-bit word, error pattern of a syndrome
 };
 
 #define FX_DEV __device__ __forceinline__
@@ -278,9 +282,20 @@ FX_DEV int conv_p(unsigned fs)   // puncturing period; 0 = not a K=7 convolution
     default: return 0;
     }
 }
+FX_DEV bool blk_spec(unsigned fs, unsigned &k, unsigned &n)    // bit-packed block codes
+{
+    switch (fs) {
+    case FX_FEC_HAMMING74: k = 4; n = 7; return true;
+    case FX_FEC_HAMMING128: k = 8; n = 12; return true;
+    case FX_FEC_GOLAY2412: k = 12; n = 24; return true;
+    default: k = n = 0; return false;
+    }
+}
 FX_DEV bool fec_supported(unsigned fs)
 {
-    return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || conv_p(fs) != 0;
+    unsigned k, n;
+    return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || fs == FX_FEC_SECDED2216 ||
+           fs == FX_FEC_SECDED3932 || blk_spec(fs, k, n) || conv_p(fs) != 0;
 }
 FX_DEV unsigned fec_enc_len(unsigned fs, unsigned n)
 {
@@ -290,6 +305,10 @@ FX_DEV unsigned fec_enc_len(unsigned fs, unsigned n)
         unsigned bits = p == 1 ? 2 * T : T + (T + (unsigned)p - 1) / (unsigned)p;
         return (bits + 7) / 8;
     }
+    unsigned bk, bn;
+    if (blk_spec(fs, bk, bn)) { unsigned nb = (8 * n + bk - 1) / bk; return (nb * bn + 7) / 8; }
+    if (fs == FX_FEC_SECDED2216) return 3 * (n / 2) + ((n % 2) ? (n % 2) + 1 : 0);
+    if (fs == FX_FEC_SECDED3932) return 5 * (n / 4) + ((n % 4) ? (n % 4) + 1 : 0);
     if (fs == FX_FEC_HAMMING84) return 2 * n;
     if (fs == FX_FEC_SECDED7264) return 9 * (n / 8) + ((n % 8) ? (n % 8) + 1 : 0);
     return n;

@@ -158,6 +158,9 @@ int upload_tables(fxrx_ctx_s *c)
     for (size_t i = 0; i < H.perm54.size(); i++) t->perm54[i] = (uint16_t)H.perm54[i];
     for (size_t i = 0; i < H.perm27.size(); i++) t->perm27[i] = (uint16_t)H.perm27[i];
     std::memcpy(t->h84dec, B.h84_dec, 256); std::memcpy(t->sdcol, B.sd_col, 64);
+    std::memcpy(t->sd22col, B.sd22_col, 16); std::memcpy(t->sd39col, B.sd39_col, 32);
+    std::memcpy(t->h74dec, B.h74_dec, 128); std::memcpy(t->h128dec, B.h128_dec, 4096);
+    std::memcpy(t->golenc, B.gol_enc, sizeof B.gol_enc); std::memcpy(t->golerr, B.gol_err, sizeof B.gol_err);
     HIP_OK(hipMalloc((void **)&c->d_tables, sizeof(FxTables)));
     HIP_OK(hipMemcpy(c->d_tables, t.get(), sizeof(FxTables), hipMemcpyHostToDevice));
     return 0;
@@ -175,9 +178,10 @@ const PlanDev &get_plan(fxrx_ctx_s *c, unsigned n, unsigned check, unsigned fec0
     return c->plans.emplace(k, pd).first->second;
 }
 
-// frame-table slots per walk job.  Kept small (the table is copied to the host every block); a segment with
-// more detections than this continues through the FX_EXIT_TABLE_FULL path.
-inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 512 + 8, 24); }
+// frame-table slots per walk job: one per 2048 samples of segment (+8).  The table is copied to the host every
+// block, so it is not sized for the densest legal traffic (a 650-sample frame); a segment with more detections than
+// slots continues through the FX_EXIT_TABLE_FULL path.
+inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 2048 + 8, 512); }
 
 int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
 {
@@ -336,7 +340,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             j.mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
             j.handoff = j.stop < ns[s] ? 1u : 0u;
             j.prelock = first ? 0u : 1u;
-            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + seg);
+            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start));
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
             c->jobs.push_back(j); c->job_stream.push_back(s);

@@ -752,22 +752,66 @@ __device__ __forceinline__ void permute_bits(const uint8_t *src, uint8_t *dst, c
     }
 }
 
+// SECDED with nd data bytes per block behind one parity byte (nd = 2, 4, 8), Hsiao columns `col`
+__device__ __forceinline__ void secded_decode(const uint8_t *col, uint32_t nd, uint32_t n, const uint8_t *enc, uint8_t *dec, int lane)
+{
+    const uint32_t nblk = (n + nd - 1) / nd;
+    for (uint32_t blk = lane; blk < nblk; blk += DEC_THREADS) {
+        const uint32_t nb = min(nd, n - nd * blk);
+        uint8_t d[8]; uint8_t par = 0;
+        for (uint32_t j = 0; j < 8; j++) d[j] = j < nb ? enc[(nd + 1) * blk + 1 + j] : 0;
+        for (uint32_t j = 0; j < 8 * nd; j++) if (d[j >> 3] & (0x80u >> (j & 7))) par ^= col[j];
+        const uint8_t syn = (uint8_t)(enc[(nd + 1) * blk] ^ par);
+        if (syn != 0 && __popc((unsigned)syn) != 1)
+            for (uint32_t j = 0; j < 8 * nd; j++) if (col[j] == syn) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); break; }
+        for (uint32_t j = 0; j < nb; j++) dec[nd * blk + j] = d[j];
+    }
+}
+
+__device__ __forceinline__ unsigned take_bits(const uint8_t *b, uint32_t nbytes, uint32_t pos, unsigned nbits)
+{
+    unsigned v = 0;
+    for (unsigned i = 0; i < nbits; i++) { const uint32_t q = pos + i; v = (v << 1) | (q < 8 * nbytes ? getbit(b, q) : 0u); }
+    return v;
+}
+
 __device__ __forceinline__ void block_fec_decode(unsigned fs, uint32_t n, const uint8_t *enc, uint8_t *dec, const FxTables *T, int lane)
 {
+    unsigned bk, bn;
     if (fs == FX_FEC_HAMMING84) {
         for (uint32_t j = lane; j < n; j += DEC_THREADS)
             dec[j] = (uint8_t)((T->h84dec[enc[2 * j]] << 4) | T->h84dec[enc[2 * j + 1]]);
     } else if (fs == FX_FEC_SECDED7264) {
-        const uint32_t nblk = (n + 7) / 8;
-        for (uint32_t blk = lane; blk < nblk; blk += DEC_THREADS) {
-            const uint32_t nb = min(8u, n - 8 * blk);
-            uint8_t d[8]; uint8_t par = 0;
-            for (uint32_t j = 0; j < 8; j++) d[j] = j < nb ? enc[9 * blk + 1 + j] : 0;
-            for (int j = 0; j < 64; j++) if (d[j >> 3] & (0x80u >> (j & 7))) par ^= T->sdcol[j];
-            uint8_t syn = (uint8_t)(enc[9 * blk] ^ par);
-            if (syn != 0 && __popc((unsigned)syn) != 1)
-                for (int j = 0; j < 64; j++) if (T->sdcol[j] == syn) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); break; }
-            for (uint32_t j = 0; j < nb; j++) dec[8 * blk + j] = d[j];
+        secded_decode(T->sdcol, 8, n, enc, dec, lane);
+    } else if (fs == FX_FEC_SECDED3932) {
+        secded_decode(T->sd39col, 4, n, enc, dec, lane);
+    } else if (fs == FX_FEC_SECDED2216) {
+        secded_decode(T->sd22col, 2, n, enc, dec, lane);
+    } else if (blk_spec(fs, bk, bn)) {
+        // bit-packed codewords: decode whole output bytes per lane (lcm(k,8)/k codewords make lcm(k,8)/8 bytes)
+        const uint32_t el = fec_enc_len(fs, n);
+        const unsigned grp_cw = bk == 4 ? 2u : (bk == 8 ? 1u : 2u);          // codewords per group
+        const unsigned grp_by = bk == 4 ? 1u : (bk == 8 ? 1u : 3u);          // output bytes per group
+        const uint32_t ngrp = (n + grp_by - 1) / grp_by;
+        for (uint32_t g = lane; g < ngrp; g += DEC_THREADS) {
+            unsigned acc = 0;
+            for (unsigned c = 0; c < grp_cw; c++) {
+                const uint32_t j = g * grp_cw + c;
+                unsigned r = take_bits(enc, el, j * bn, bn), d;
+                if (fs == FX_FEC_HAMMING74) d = T->h74dec[r];
+                else if (fs == FX_FEC_HAMMING128) d = T->h128dec[r];
+                else {
+                    const unsigned syn = (T->golenc[(r >> 12) & 0xfff] ^ r) & 0xfff;
+                    const uint32_t e = T->golerr[syn];
+                    if (e != 0xFFFFFFFFu) r ^= e;
+                    d = (r >> 12) & 0xfff;
+                }
+                acc = (acc << bk) | d;
+            }
+            for (unsigned b = 0; b < grp_by; b++) {
+                const uint32_t o = g * grp_by + b;
+                if (o < n) dec[o] = (uint8_t)(acc >> (8 * (grp_by - 1 - b)));
+            }
         }
     } else {
         for (uint32_t j = lane; j < n; j += DEC_THREADS) dec[j] = enc[j];

@@ -11,8 +11,9 @@
  * Restatement notes (all inside "parity unpinned"):
  *  - CRCs are the clean reflected forms (register masked to its width); liquid keeps a 32-bit
  *    register for the 8/16/24-bit keys.
- *  - Hamming(8,4) and SECDED(72,64) use textbook constructions (systematic extended Hamming;
- *    Hsiao odd-weight columns), not liquid's literal generator tables, which are not recalled.
+ *  - Hamming(7,4)/(8,4)/(12,8), Golay(24,12) and SECDED(22,16)/(39,32)/(72,64) use textbook constructions
+ *    (systematic / positional Hamming, cyclic Golay with g = 0xC75 + overall parity, Hsiao odd-weight columns),
+ *    not liquid's literal generator tables, which are not recalled.  Reed-Solomon (RS_M8) is not built.
  *  - Viterbi: K=7 (0x6d,0x4f), hard decisions, Hamming branch metric, punctured positions cost 0,
  *    ties keep the lower predecessor, traceback from state 0.  libfec's 8-bit soft metric on
  *    0/255 inputs selects the same path except on exact metric ties.
@@ -163,6 +164,140 @@ static void sd_decode_block(const uint8_t e[9], uint8_t d[8])
     /* double error: detected, left uncorrected */
 }
 
+/* ---------------------------------------------------------------- SECDED(22,16) and SECDED(39,32): same shape as (72,64) */
+static uint8_t sd22_col[16], sd39_col[32];
+static int sdx_ready = 0;
+static void sdx_init(void)
+{
+    if (sdx_ready) return;
+    unsigned n = 0;
+    for (unsigned v = 1; v < 64 && n < 16; v++) if (__builtin_popcount(v) == 3) sd22_col[n++] = (uint8_t)v;
+    n = 0;
+    for (unsigned v = 1; v < 128 && n < 32; v++) if (__builtin_popcount(v) == 3) sd39_col[n++] = (uint8_t)v;
+    sdx_ready = 1;
+}
+/* nd data bytes, one leading parity byte holding a (cols-wide) Hsiao parity */
+static uint8_t sdx_parity(const uint8_t *col, const uint8_t *d, unsigned nd)
+{
+    uint8_t p = 0;
+    for (unsigned j = 0; j < 8 * nd; j++) if (d[j >> 3] & (0x80u >> (j & 7))) p ^= col[j];
+    return p;
+}
+static void sdx_encode(const uint8_t *col, unsigned nd, unsigned n, const uint8_t *dec, uint8_t *enc)
+{
+    unsigned i = 0, j = 0;
+    for (; i + nd <= n; i += nd, j += nd + 1) { enc[j] = sdx_parity(col, dec + i, nd); memcpy(enc + j + 1, dec + i, nd); }
+    if (n % nd) { uint8_t d[8] = { 0 }; memcpy(d, dec + i, n % nd); enc[j] = sdx_parity(col, d, nd); memcpy(enc + j + 1, d, n % nd); }
+}
+static void sdx_decode_block(const uint8_t *col, unsigned nd, const uint8_t *e, uint8_t *d)
+{
+    memcpy(d, e + 1, nd);
+    uint8_t s = (uint8_t)(e[0] ^ sdx_parity(col, d, nd));
+    if (s == 0 || __builtin_popcount(s) == 1) return;
+    for (unsigned j = 0; j < 8 * nd; j++) if (col[j] == s) { d[j >> 3] ^= (uint8_t)(0x80u >> (j & 7)); return; }
+}
+static void sdx_decode(const uint8_t *col, unsigned nd, unsigned n, const uint8_t *enc, uint8_t *dec)
+{
+    unsigned i = 0, j = 0;
+    for (; i + nd <= n; i += nd, j += nd + 1) sdx_decode_block(col, nd, enc + j, dec + i);
+    if (n % nd) { uint8_t e[9] = { 0 }, d[8]; memcpy(e, enc + j, n % nd + 1); sdx_decode_block(col, nd, e, d); memcpy(dec + i, d, n % nd); }
+}
+
+/* ---------------------------------------------------------------- bit-packed block codes: Hamming(7,4), Hamming(12,8), Golay(24,12)
+ * k-bit blocks are taken MSB first from the byte stream (last one zero padded), each becomes an n-bit codeword,
+ * codewords are written MSB first back to back.  Decoding is nearest-codeword through syndrome tables. */
+static uint8_t  h74_enc[16], h74_dec[128];
+static uint16_t h128_enc[256]; static uint8_t h128_dec[4096];
+static uint32_t gol_enc[4096], gol_err[4096];            /* codeword of a 12-bit word; error pattern of a syndrome */
+static int blk_ready = 0;
+static unsigned gol_syndrome(uint32_t cw)                 /* parity part recomputed from the data part, xor received parity */
+{
+    return (unsigned)((gol_enc[(cw >> 12) & 0xfff] ^ cw) & 0xfff);
+}
+static void blk_init(void)
+{
+    if (blk_ready) return;
+    for (unsigned d = 0; d < 16; d++) {                    /* systematic (7,4): d3 d2 d1 d0 p2 p1 p0 */
+        unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
+        h74_enc[d] = (uint8_t)((d << 3) | ((d1 ^ d2 ^ d3) << 2) | ((d0 ^ d2 ^ d3) << 1) | (d0 ^ d1 ^ d3));
+    }
+    for (unsigned r = 0; r < 128; r++) { unsigned best = 0, bd = 99; for (unsigned d = 0; d < 16; d++) { unsigned w = (unsigned)__builtin_popcount(r ^ h74_enc[d]); if (w < bd) { bd = w; best = d; } } h74_dec[r] = (uint8_t)best; }
+    for (unsigned d = 0; d < 256; d++) {                   /* (12,8): data bits at positions 3,5,6,7,9,10,11,12 (1-based), parity at 1,2,4,8 */
+        static const unsigned pos[8] = { 3, 5, 6, 7, 9, 10, 11, 12 };
+        unsigned cw = 0;
+        for (unsigned i = 0; i < 8; i++) if (d & (0x80u >> i)) cw |= 1u << (12 - pos[i]);
+        for (unsigned pb = 1; pb <= 8; pb <<= 1) {
+            unsigned par = 0;
+            for (unsigned q = 1; q <= 12; q++) if ((q & pb) && (cw & (1u << (12 - q)))) par ^= 1;
+            if (par) cw |= 1u << (12 - pb);
+        }
+        h128_enc[d] = (uint16_t)cw;
+    }
+    for (unsigned r = 0; r < 4096; r++) { unsigned best = 0, bd = 99; for (unsigned d = 0; d < 256; d++) { unsigned w = (unsigned)__builtin_popcount(r ^ h128_enc[d]); if (w < bd) { bd = w; best = d; } } h128_dec[r] = (uint8_t)best; }
+    for (unsigned d = 0; d < 4096; d++) {                  /* extended Golay: 12 data bits, 11 CRC-like parity bits (g = 0xC75), overall parity */
+        uint32_t reg = d << 11;
+        for (int i = 22; i >= 11; i--) if (reg & (1u << i)) reg ^= 0xC75u << (i - 11);
+        uint32_t cw23 = (d << 11) | (reg & 0x7ff);
+        gol_enc[d] = (cw23 << 1) | ((uint32_t)__builtin_popcount(cw23) & 1u);
+    }
+    for (unsigned i = 0; i < 4096; i++) gol_err[i] = 0xFFFFFFFFu;
+    /* all error patterns of weight <= 3 over 24 bits, lowest weight first; first writer of a syndrome wins */
+    gol_err[0] = 0;
+    for (int w = 1; w <= 3; w++)
+        for (int a = 0; a < 24; a++) for (int b = (w >= 2 ? a + 1 : 24); b <= 24; b++) for (int c = (w >= 3 ? b + 1 : 24); c <= 24; c++) {
+            if ((w >= 2 && b >= 24) || (w >= 3 && c >= 24)) continue;
+            uint32_t e = 1u << a; if (w >= 2) e |= 1u << b; if (w >= 3) e |= 1u << c;
+            unsigned syn = gol_syndrome(e);
+            if (gol_err[syn] == 0xFFFFFFFFu) gol_err[syn] = e;
+            if (w < 3) break;
+        }
+    blk_ready = 1;
+}
+static inline unsigned take_bits(const uint8_t *b, unsigned nbytes, unsigned pos, unsigned n)
+{
+    unsigned v = 0;
+    for (unsigned i = 0; i < n; i++) { unsigned k = pos + i; v = (v << 1) | (k < 8 * nbytes ? (b[k >> 3] >> (7 - (k & 7))) & 1u : 0u); }
+    return v;
+}
+static inline void put_bits(uint8_t *b, unsigned nbytes, unsigned pos, unsigned n, unsigned v)
+{
+    for (unsigned i = 0; i < n; i++) { unsigned k = pos + i; if (k < 8 * nbytes && ((v >> (n - 1 - i)) & 1u)) b[k >> 3] |= (uint8_t)(0x80u >> (k & 7)); }
+}
+static int blk_spec(int fs, unsigned *k, unsigned *n)
+{
+    switch (fs) {
+    case FXR_FEC_HAMMING74: *k = 4; *n = 7; return 1;
+    case FXR_FEC_HAMMING128: *k = 8; *n = 12; return 1;
+    case FXR_FEC_GOLAY2412: *k = 12; *n = 24; return 1;
+    default: return 0;
+    }
+}
+static unsigned blk_enc_len(unsigned k, unsigned n, unsigned dec_len) { unsigned nb = (8 * dec_len + k - 1) / k; return (nb * n + 7) / 8; }
+static void blk_encode(int fs, unsigned dec_len, const uint8_t *dec, uint8_t *enc)
+{
+    unsigned k, n; blk_spec(fs, &k, &n); blk_init();
+    unsigned nb = (8 * dec_len + k - 1) / k, el = blk_enc_len(k, n, dec_len);
+    memset(enc, 0, el);
+    for (unsigned j = 0; j < nb; j++) {
+        unsigned d = take_bits(dec, dec_len, j * k, k);
+        unsigned cw = fs == FXR_FEC_HAMMING74 ? h74_enc[d] : fs == FXR_FEC_HAMMING128 ? h128_enc[d] : gol_enc[d];
+        put_bits(enc, el, j * n, n, cw);
+    }
+}
+static void blk_decode(int fs, unsigned dec_len, const uint8_t *enc, uint8_t *dec)
+{
+    unsigned k, n; blk_spec(fs, &k, &n); blk_init();
+    unsigned nb = (8 * dec_len + k - 1) / k, el = blk_enc_len(k, n, dec_len);
+    memset(dec, 0, dec_len);
+    for (unsigned j = 0; j < nb; j++) {
+        unsigned r = take_bits(enc, el, j * n, n), d;
+        if (fs == FXR_FEC_HAMMING74) d = h74_dec[r];
+        else if (fs == FXR_FEC_HAMMING128) d = h128_dec[r];
+        else { uint32_t e = gol_err[gol_syndrome(r)]; if (e != 0xFFFFFFFFu) r ^= e; d = (r >> 12) & 0xfff; }
+        put_bits(dec, dec_len, j * k, k, d);
+    }
+}
+
 /* ---------------------------------------------------------------- convolutional K=7 r=1/2 (+puncturing) */
 #define V27_A 0x6d
 #define V27_B 0x4f
@@ -247,14 +382,20 @@ static void conv_decode(const punc_t *pp, unsigned dec_len, const uint8_t *enc, 
 /* ---------------------------------------------------------------- FEC dispatch */
 int fxr_fec_supported(int fs)
 {
-    return fs == FXR_FEC_NONE || fs == FXR_FEC_HAMMING84 || fs == FXR_FEC_SECDED7264 || punc_of(fs) != NULL;
+    unsigned k, n;
+    return fs == FXR_FEC_NONE || fs == FXR_FEC_HAMMING84 || fs == FXR_FEC_SECDED7264 || fs == FXR_FEC_SECDED2216 ||
+           fs == FXR_FEC_SECDED3932 || blk_spec(fs, &k, &n) || punc_of(fs) != NULL;
 }
 
 unsigned fxr_fec_enc_len(int fs, unsigned n)
 {
     const punc_t *pp = punc_of(fs);
     if (pp) return (conv_enc_bits(pp, n) + 7) / 8;
+    unsigned bk, bn;
+    if (blk_spec(fs, &bk, &bn)) return blk_enc_len(bk, bn, n);
     switch (fs) {
+    case FXR_FEC_SECDED2216: return 3 * (n / 2) + ((n % 2) ? (n % 2) + 1 : 0);
+    case FXR_FEC_SECDED3932: return 5 * (n / 4) + ((n % 4) ? (n % 4) + 1 : 0);
     case FXR_FEC_HAMMING84: return 2 * n;
     case FXR_FEC_SECDED7264: return 9 * (n / 8) + ((n % 8) ? (n % 8) + 1 : 0);
     default: return n;
@@ -265,7 +406,11 @@ void fxr_fec_encode(int fs, unsigned n, const uint8_t *dec, uint8_t *enc)
 {
     const punc_t *pp = punc_of(fs);
     if (pp) { conv_encode(pp, n, dec, enc); return; }
+    unsigned bk, bn;
+    if (blk_spec(fs, &bk, &bn)) { blk_encode(fs, n, dec, enc); return; }
     switch (fs) {
+    case FXR_FEC_SECDED2216: sdx_init(); sdx_encode(sd22_col, 2, n, dec, enc); return;
+    case FXR_FEC_SECDED3932: sdx_init(); sdx_encode(sd39_col, 4, n, dec, enc); return;
     case FXR_FEC_HAMMING84:
         h84_init();
         for (unsigned i = 0; i < n; i++) { enc[2 * i] = h84_enc[dec[i] >> 4]; enc[2 * i + 1] = h84_enc[dec[i] & 15]; }
@@ -287,7 +432,11 @@ void fxr_fec_decode(int fs, unsigned n, const uint8_t *enc, uint8_t *dec)
 {
     const punc_t *pp = punc_of(fs);
     if (pp) { conv_decode(pp, n, enc, dec); return; }
+    unsigned bk, bn;
+    if (blk_spec(fs, &bk, &bn)) { blk_decode(fs, n, enc, dec); return; }
     switch (fs) {
+    case FXR_FEC_SECDED2216: sdx_init(); sdx_decode(sd22_col, 2, n, enc, dec); return;
+    case FXR_FEC_SECDED3932: sdx_init(); sdx_decode(sd39_col, 4, n, enc, dec); return;
     case FXR_FEC_HAMMING84:
         h84_init();
         for (unsigned i = 0; i < n; i++) dec[i] = (uint8_t)((h84_dec[enc[2 * i]] << 4) | h84_dec[enc[2 * i + 1]]);

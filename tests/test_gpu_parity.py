@@ -54,7 +54,8 @@ def test_all_modulations_and_codes_batched(fx, oracle):
 
 def test_outer_block_codes_and_checks(fx, oracle):
     xs = []
-    for i, (f0, f1, chk) in enumerate([(1, 5, 6), (11, 10, 4), (20, 5, 3), (1, 10, 2), (15, 1, 1)]):
+    for i, (f0, f1, chk) in enumerate([(1, 5, 6), (11, 10, 4), (20, 5, 3), (1, 10, 2), (15, 1, 1),
+                                       (11, 7, 5), (1, 4, 5), (15, 6, 5), (17, 8, 6), (1, 9, 5), (19, 7, 4)]):
         x, _ = fx.synth_stream(40_000, stream_id=300 + i, mod=27, fec0=f0, fec1=f1, check=chk, payload_len=257, snr_db=30.0)
         xs.append(x)
     ctx = fx.RxContext(len(xs), want_framesyms=True)
@@ -235,3 +236,26 @@ def test_config3_and_config4_shapes_scaled(fx, oracle):
             assert any(abs(p - q) <= 1 for q in pos)
     od = oracle.Detector(0.45).run(xs[5])
     assert [d["pos"] for d in od] == [g["start"] for g in gd if g["stream"] == 5]
+
+
+def test_pipelined_submit_collect_equals_blocking(fx, oracle):
+    """Several blocks in flight (fxrx_submit / fxrx_collect) must give exactly what one-block-at-a-time gives,
+    including state carried from block to block of the same stream."""
+    x, inj = fx.synth_stream(600_000, stream_id=71, payload_len=400)
+    of = oracle_frames(oracle, x)
+    blocks = [x[i:i + 75_000] for i in range(0, len(x), 75_000)]
+    ref_ctx = fx.RxContext(1, want_framesyms=True)
+    ref = sum((ref_ctx.process([b]) for b in blocks), [])
+    ctx = fx.RxContext(1, want_framesyms=True)
+    ctx.set_depth(3)
+    got, inflight = [], 0
+    for b in blocks:
+        if inflight == 3:
+            got += ctx.results(ctx.collect_raw()); inflight -= 1
+        ctx.submit_raw([b.ctypes.data], [len(b)], False); inflight += 1
+    while inflight:
+        got += ctx.results(ctx.collect_raw()); inflight -= 1
+    compare_frames(of, got)
+    assert [(g["start"], g["payload"], g["evm_sum"]) for g in got] == [(g["start"], g["payload"], g["evm_sum"]) for g in ref]
+    with pytest.raises(fx.rx.RxError):
+        ctx.collect_raw()                                      # nothing in flight
