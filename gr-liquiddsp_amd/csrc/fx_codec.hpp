@@ -382,7 +382,12 @@ inline unsigned modem_bps(unsigned ms)
 struct Modulator {
     unsigned ms, bps, dpsk_idx = 0; const cf *sc;
     Modulator(unsigned ms_, const cf *sincos1024) : ms(ms_), bps(modem_bps(ms_)), sc(sincos1024) {}
-    cf psk(unsigned i) const { return sc[(i << (32 - bps)) >> 22]; }
+    cf psk(unsigned i) const
+    {
+        static const cf axis[4] = { { 1.0f, 0.0f }, { 0.0f, 1.0f }, { -1.0f, 0.0f }, { 0.0f, -1.0f } };   // exact for M <= 4
+        if (bps <= 2) return axis[bps == 1 ? 2 * (i & 1) : (i & 3)];
+        return sc[(i << (32 - bps)) >> 22];
+    }
     cf mod(unsigned sym)
     {
         const float h = 0.70710678118654752f;

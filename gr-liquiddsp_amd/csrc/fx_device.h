@@ -53,10 +53,10 @@ FX_DEV uint32_t rad2u32(float rad)
     return (uint32_t)(long long)t;
 }
 
-// PLL increments: clamp, then a plain 32-bit convert (same value as the wrapping form for |x| < pi)
-FX_DEV uint32_t rad2u32s(float rad)
+// PLL increments, already in phase units: round, clamp below 2^31, plain 32-bit convert
+FX_DEV uint32_t phase_inc(float units)
 {
-    float t = rintf(rad * 683565248.0f);
+    float t = rintf(units);
     t = fminf(fmaxf(t, -2147483520.0f), 2147483520.0f);
     return (uint32_t)(int)t;
 }
@@ -213,6 +213,16 @@ FX_DEV unsigned psk_index(float2 r, unsigned bps)
     return (unsigned)((int)t) & ((1u << bps) - 1u);
 }
 
+// unit phasor at phase index idx of 2^bps: exact axis points up to 4-PSK, the sincos table beyond
+FX_DEV float2 psk_point(unsigned idx, unsigned bps, const float2 *sc)
+{
+    if (bps <= 2) {
+        const unsigned q = bps == 1 ? 2u * (idx & 1u) : (idx & 3u);
+        return make_float2(q == 0 ? 1.0f : (q == 2 ? -1.0f : 0.0f), q == 1 ? 1.0f : (q == 3 ? -1.0f : 0.0f));
+    }
+    return sc[(idx << (32 - bps)) >> 22];
+}
+
 // dpsk_prev: running phase index of differential schemes (in/out)
 FX_DEV unsigned modem_demod(unsigned ms, unsigned bps, float2 r, unsigned &dpsk_prev, const float2 *sc,
                             float2 &xh, float &pe)
@@ -226,12 +236,12 @@ FX_DEV unsigned modem_demod(unsigned ms, unsigned bps, float2 r, unsigned &dpsk_
         break;
     case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: {
         unsigned idx = psk_index(r, bps);
-        sym = gray_enc(idx); xh = sc[(idx << (32 - bps)) >> 22];
+        sym = gray_enc(idx); xh = psk_point(idx, bps, sc);
         break; }
     case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8: {
         unsigned idx = psk_index(r, bps);
         sym = gray_enc((idx - dpsk_prev) & ((1u << bps) - 1u));
-        dpsk_prev = idx; xh = sc[(idx << (32 - bps)) >> 22];
+        dpsk_prev = idx; xh = psk_point(idx, bps, sc);
         break; }
     case FX_MODEM_ASK4: {
         unsigned idx = pam_index(r.x, 1.11803399f, 4);

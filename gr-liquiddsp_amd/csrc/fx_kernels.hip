@@ -644,16 +644,27 @@ __device__ __forceinline__ void pll_load8(const float4 *p, float4 b[4]) { b[0] =
 // One instantiation per modulation scheme: the demodulator is resolved at compile time, so the loop body is
 // straight-line code (the host launches one grid per scheme present in the batch, over an index list).
 template <int MS>
-__device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const float2 *sc, float2 q0, float2 q1, float2 q2, float2 q3,
-                                             float2 &xh, float &pe)
+__device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const float2 *sc, float2 &xh, float &pe)
 {
     if constexpr (MS == FX_MODEM_PSK2 || MS == FX_MODEM_PSK4) {
-        unsigned idx, pi4;
-        if constexpr (MS == FX_MODEM_PSK2) { idx = r.x > 0.0f ? 0u : 1u; pi4 = 2u * idx; }
-        else { idx = (fabsf(r.x) >= fabsf(r.y)) ? (r.x > 0.0f ? 0u : 2u) : (r.y > 0.0f ? 1u : 3u); pi4 = idx; }
-        xh = pi4 == 0 ? q0 : (pi4 == 1 ? q1 : (pi4 == 2 ? q2 : q3));
-        float pr = fmaf(r.x, xh.x, r.y * xh.y);
-        float pim = fmaf(r.y, xh.x, -(r.x * xh.y));
+        // decision regions are the axes' half-planes / quadrants about them; with the exact axis points the rotation
+        // r conj(xhat) is a swap / sign flip (bit-identical to the general fma form)
+        unsigned idx; float pr, pim;
+        if constexpr (MS == FX_MODEM_PSK2) {
+            const bool neg = !(r.x > 0.0f);
+            idx = neg ? 1u : 0u;
+            xh = make_float2(neg ? -1.0f : 1.0f, 0.0f);
+            pr = neg ? -r.x : r.x; pim = neg ? -r.y : r.y;
+        } else {
+            const bool horiz = fabsf(r.x) >= fabsf(r.y);
+            const bool neg = horiz ? !(r.x > 0.0f) : !(r.y > 0.0f);
+            idx = (horiz ? 0u : 1u) + (neg ? 2u : 0u);
+            const float sg = neg ? -1.0f : 1.0f;
+            xh = horiz ? make_float2(sg, 0.0f) : make_float2(0.0f, sg);
+            // horiz: r * conj(+-1) = +-(x, y);  vertical: r * conj(+-j) = +-(y, -x)
+            const float a = horiz ? r.x : r.y, b = horiz ? r.y : -r.x;
+            pr = neg ? -a : a; pim = neg ? -b : b;
+        }
         pe = atan2c(pim, pr);
         return gray_enc(idx);
     } else {
@@ -683,9 +694,9 @@ void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
     const float4 *in = reinterpret_cast<const float4 *>(sym_raw + job.sym_off);      // sym_off is a multiple of 8
     float4 *out = reinterpret_cast<float4 *>(framesyms + job.sym_off);
     uint2 *hd = reinterpret_cast<uint2 *>(hard + job.sym_off);
-    uint32_t th = job.pll_th; float fq = job.pll_f, evm = 0.0f; unsigned prev = 0;
+    // loop state: phase (2^32 = one turn), frequency in the same units per symbol, EVM accumulator
+    uint32_t th = job.pll_th; float fq = job.pll_f * 683565248.0f, evm = 0.0f; unsigned prev = 0;
     const unsigned nsym = job.nsym;
-    const float2 q0 = sc[0], q1 = sc[256], q2 = sc[512], q3 = sc[768];
     const uint32_t nblk = (nsym + PLL_BLK - 1) / PLL_BLK;
     float4 cur[4], nxt[4];
     if (nblk) pll_load8(in, cur);
@@ -699,13 +710,12 @@ void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
             const float2 y = (k & 1) ? make_float2(v4.z, v4.w) : make_float2(v4.x, v4.y);
             float2 r = derot(y, th, sc), xh; float pe;
             unsigned pv = prev;
-            const unsigned s = pll_demod<MS>(r, pv, sc, q0, q1, q2, q3, xh, pe);
+            const unsigned s = pll_demod<MS>(r, pv, sc, xh, pe);
             if ((unsigned)k < live) {                                          // tail of the last block: state frozen
                 float dr = r.x - xh.x, di = r.y - xh.y;
                 evm += fmaf(dr, dr, di * di);
-                fq += pe * 1e-4f;
-                th += rad2u32s(pe * 0.01f);
-                th += rad2u32s(fq);
+                fq = fmaf(pe, 68356.5248f, fq);                                // alpha = 1e-4 (x 2^32/2pi)
+                th += phase_inc(pe * 6835652.5f) + phase_inc(fq);              // beta = 1e-2 (x 2^32/2pi), then advance
                 prev = pv;
             }
             rr[2 * k] = r.x; rr[2 * k + 1] = r.y;

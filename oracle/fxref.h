@@ -78,7 +78,7 @@ enum {
 /* ------------------------------------------------------------------ math (fxref_math.c) */
 void     fxr_init(void);                        /* builds all shared tables once (idempotent) */
 uint32_t fxr_rad2u32(float rad);                /* rintf(rad * 2^32/2pi) wrapped mod 2^32 */
-uint32_t fxr_rad2u32s(float rad);               /* same, |result| clamped below 2^31: PLL increments */
+uint32_t fxr_phase_inc(float units);            /* rintf(units) clamped below 2^31: PLL increments in phase units */
 void     fxr_sincos_u32(uint32_t th, float *c, float *s);
 float    fxr_atan2(float y, float x);
 float    fxr_sum_tree(const float *v, unsigned n);          /* n power of two */

@@ -432,7 +432,7 @@ static void sync_decode_header(fxr_sync *q)
     }
     q->pay_dec = (uint8_t *)realloc(q->pay_dec, q->pay_len + 8);
     fxr_modem_init(&q->demod, q->ms);
-    q->pll_f = dphi;
+    q->pll_f = dphi * 683565248.0f;             /* rad/symbol -> phase units/symbol */
     q->pll_th = ph + dl * FXR_HDR_SYM;
     q->evm_sum = 0.0f; q->pay_counter = 0;
     q->state = FS_PAYLOAD;
@@ -453,9 +453,9 @@ static void sync_on_symbol(fxr_sync *q, fxr_c32 y)
     unsigned s = fxr_modem_demod(&q->demod, r, &xh, &pe);
     float dr = r.re - xh.re, di = r.im - xh.im;
     q->evm_sum += fmaf(dr, dr, di * di);
-    q->pll_f += pe * 1e-4f;
-    q->pll_th += fxr_rad2u32s(pe * 0.01f);
-    q->pll_th += fxr_rad2u32s(q->pll_f);
+    /* loop filter kept in phase units: alpha = 1e-4 and beta = 1e-2 pre-multiplied by 2^32/2pi */
+    q->pll_f = fmaf(pe, 68356.5248f, q->pll_f);
+    q->pll_th += fxr_phase_inc(pe * 6835652.5f) + fxr_phase_inc(q->pll_f);
     q->pay_sym[q->pay_counter] = r; q->pay_hard[q->pay_counter] = (uint8_t)s;
     if (++q->pay_counter == q->pay_sym_len) sync_decode_payload(q);
 }

@@ -41,10 +41,10 @@ uint32_t fxr_rad2u32(float rad)
     return (uint32_t)(int64_t)t;
 }
 
-/* PLL increments are tiny; clamp so that a 32-bit convert is exact and saturation-free on any input */
-uint32_t fxr_rad2u32s(float rad)
+/* PLL increments, already in phase units (2^32 = one turn); clamp so that a 32-bit convert is exact on any input */
+uint32_t fxr_phase_inc(float units)
 {
-    float t = rintf(rad * 683565248.0f);
+    float t = rintf(units);
     t = fminf(fmaxf(t, -2147483520.0f), 2147483520.0f);
     return (uint32_t)(int32_t)t;
 }

@@ -42,10 +42,15 @@ static void qam_dims(int ms, unsigned *mi, unsigned *mq, float *alpha)
     }
 }
 
-/* unit phasor at phase index i of M via the shared 32-bit-phase sincos */
+/* unit phasor at phase index i of M: exact axis points for M <= 4, the shared sincos table beyond */
 static fxr_c32 psk_point(unsigned i, unsigned bps)
 {
-    fxr_c32 p; fxr_sincos_u32((uint32_t)i << (32 - bps), &p.re, &p.im);
+    fxr_c32 p;
+    if (bps <= 2) {
+        static const fxr_c32 axis[4] = { { 1.0f, 0.0f }, { 0.0f, 1.0f }, { -1.0f, 0.0f }, { 0.0f, -1.0f } };
+        return axis[bps == 1 ? 2 * (i & 1) : (i & 3)];
+    }
+    fxr_sincos_u32((uint32_t)i << (32 - bps), &p.re, &p.im);
     return p;
 }
 
