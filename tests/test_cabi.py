@@ -117,3 +117,15 @@ def test_synth_stream_is_deterministic(fx):
     c, _ = fx.synth_stream(60000, stream_id=6)
     assert np.array_equal(a, b) and fa == fb and not np.array_equal(a, c)
     assert len(fa) == 3 and fa[1][0] - fa[0][0] == 17066 + 256
+
+
+def test_cpp_block_shells_compile_against_the_header(fx, tmp_path):
+    """csrc/blocks/fx_blocks.hpp needs nothing but include/fxrx.h and -lfxrx; without a GPU construction throws."""
+    import subprocess
+    exe = str(tmp_path / "test_blocks")
+    lib = os.path.join(ROOT, "gr-liquiddsp_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_blocks.cpp"),
+                           "-L" + lib, "-lfxrx", "-Wl,-rpath," + lib])
+    if fx.lib().fxrx_device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode != 0 and "no usable HIP device" in r.stderr
