@@ -89,7 +89,7 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -140,17 +140,23 @@ def main():
     # through the submit/collect pipeline (depth 3) the way a streaming receiver feeds consecutive blocks
     depth = 1 if a.no_pipeline else a.depth
     ctx.set_depth(depth)
+
+    def run_steps(k):
+        inflight, last = 0, 0
+        for _ in range(k):
+            if inflight == depth:
+                last = ctx.collect_raw(); inflight -= 1
+            ctx.reset()
+            ctx.submit_raw(ptrs, counts, True); inflight += 1
+        while inflight:
+            last = ctx.collect_raw(); inflight -= 1
+        return last
+
+    run_steps(max(a.warmup, 1) * 4)                      # untimed warm-up of the pipelined path itself
     if world > 1: dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    inflight = 0
-    for _ in range(a.steps):
-        if inflight == depth:
-            nres = ctx.collect_raw(); inflight -= 1
-        ctx.reset()
-        ctx.submit_raw(ptrs, counts, True); inflight += 1
-    while inflight:
-        nres = ctx.collect_raw(); inflight -= 1
+    nres = run_steps(a.steps)
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
     dt = time.perf_counter() - t0

@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libfxrx.so")
+LIB_PATH = os.environ.get("FXRX_LIB", os.path.join(CSRC, "libfxrx.so"))   # FXRX_LIB: A/B builds during tuning
 
 
 class FxComplex(C.Structure):

@@ -31,6 +31,13 @@
 #define FX_SYM0_HDR      78      /* 2m + 64 */
 #define FX_SYM0_PAY      309
 
+// waves per walker workgroup (build-time: 4 or 8).  8 halves the latency of a detector hop (49 CFO-sweep
+// transforms in 7 rounds instead of 13) at one workgroup per CU; 4 leaves room for two per CU.
+#ifndef FX_WALK_WAVES
+#define FX_WALK_WAVES 8
+#endif
+#define FX_WALK_THREADS (64 * FX_WALK_WAVES)
+
 // header-stored enums (liquid.h v1.3.x numbering, recalled; see include/fxrx.h)
 enum { FX_CRC_UNKNOWN = 0, FX_CRC_NONE, FX_CRC_CHECKSUM, FX_CRC_8, FX_CRC_16, FX_CRC_24, FX_CRC_32 };
 enum {

@@ -187,7 +187,7 @@ int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
 {
     std::memcpy(c->hp_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob));
     HIP_OK(hipMemcpyAsync(c->d_jobs.p + first, c->hp_jobs.p + first, count * sizeof(FxWalkJob), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(fx_walk_kernel, dim3((unsigned)count), dim3(256), 0, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables);
+    hipLaunchKernelGGL(fx_walk_kernel, dim3((unsigned)count), dim3(FX_WALK_THREADS), 0, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -223,7 +223,22 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
     if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(4, std::max(1, std::atoi(e)));
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+    {
+        // The walker fills every CU it may use (8 waves x 256 VGPRs = one register file).  Keeping it off a few CUs
+        // (FXRX_WALK_CUS of the device's CUs, default all but 32) leaves room where the latency-critical PLL / decode
+        // waves of the blocks in flight always find a slot at once.
+        hipDeviceProp_t prop; int ncu = 256;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ncu = prop.multiProcessorCount;
+        int want = ncu > 64 ? ncu - 32 : ncu;
+        if (const char *e = std::getenv("FXRX_WALK_CUS")) want = std::atoi(e);
+        hipError_t err;
+        if (want > 0 && want < ncu) {
+            std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+            for (int i = 0; i < want; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+            err = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
+        } else err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+        if (err != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+    }
     for (unsigned i = 0; i < c->n_pstreams; i++)
         if (hipStreamCreateWithFlags(&c->stream_p[i], hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
     if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
@@ -316,9 +331,9 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     uint64_t seg = c->cfg.segment_len;
     if (seg == 0) {
         uint64_t tot = 0; for (unsigned s = 0; s < NS; s++) tot += (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
-        // ~1.5 walker workgroups per CU: a single wave of workgroups (2 fit per CU) with room left for the
-        // payload kernels of other blocks in flight
-        seg = tot / 384;
+        // one walker workgroup (8 waves, the whole register file) per CU, a few CUs left free for the payload
+        // kernels of other blocks in flight
+        seg = tot / (FX_WALK_WAVES == 8 ? 240 : 384);
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
     }
     seg = std::max<uint64_t>(seg, 4096);

@@ -21,8 +21,11 @@
 #include <hip/hip_runtime.h>
 #include "fx_device.h"
 
-#define WALK_THREADS 256
-#define WALK_WAVES   4
+// 8 waves: the 49 CFO-sweep transforms of a hop take 7 rounds instead of 13.  The 512-sample window is still
+// handled by the first 256 threads (HALF); reductions keep the 4-wave tree order of the canonical arithmetic.
+#define WALK_THREADS FX_WALK_THREADS
+#define WALK_WAVES   FX_WALK_WAVES
+#define HALF         256
 
 struct WalkLds {
     float2 win[FX_NFFT];            // time window of the current hop / aligned window
@@ -33,13 +36,14 @@ struct WalkLds {
     float2 P[256];                  // x conj(s) products (ALIGN)
     float  m2[FX_NFFT];
     float2 hdr[FX_HDR_SYM];
-    float2 cw[5 * FX_HOP + 8];      // coarse pre-lock scan: overlap half + four new hops
+    float2 cw[9 * FX_HOP + 8];      // coarse pre-lock scan: overlap half + eight new hops
     float2 pb[16];                  // de-rotated pilots
     float  taps[FX_MF_TAPS];
     float  redf[WALK_WAVES]; float2 redc[WALK_WAVES];
     float  redv[WALK_WAVES]; uint32_t redk[WALK_WAVES];
     float  f[16];                   // scalar broadcast slots
     uint32_t u[16];
+    uint32_t cand[WALK_WAVES];
     uint8_t hs[FX_HDR_MOD];
     uint8_t b0[64], b1[64];
 };
@@ -47,7 +51,7 @@ struct WalkLds {
 // ---- workgroup reductions (all 256 threads call; result on every thread) ----
 __device__ __forceinline__ float block_sum256(float v, WalkLds &L, int lane, int wave)
 {
-    v = wave_sum(v);
+    v = wave_sum(v);                       // callers pass 0 from threads >= HALF; only waves 0-3 enter the tree
     __syncthreads();
     if (lane == 0) L.redf[wave] = v;
     __syncthreads();
@@ -135,7 +139,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     float2 twA[7], twB[7];
 #pragma unroll
     for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
-    L.S[tid] = T->S[tid]; L.S[tid + 256] = T->S[tid + 256];
+    for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
 
     int64_t pos = job.start, floor_ = job.floor;
     bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
@@ -151,8 +155,9 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     const float s2sum = T->s2sum;
     const float2 *sc = T->sc;
 
-    if (fresh) L.win[tid] = make_float2(0.0f, 0.0f);
-    else { float2 w = xv(x, pos - FX_HOP + tid, floor_, n); L.win[tid] = w; x2_0 = block_sum256(cm2(w), L, lane, wave); }
+    const bool lo = tid < HALF;            // threads that own one sample of a 256-sample half
+    if (fresh) { if (lo) L.win[tid] = make_float2(0.0f, 0.0f); }
+    else { float2 w = lo ? xv(x, pos - FX_HOP + tid, floor_, n) : make_float2(0.0f, 0.0f); if (lo) L.win[tid] = w; x2_0 = block_sum256(cm2(w), L, lane, wave); }
     __syncthreads();
 
     for (;;) {
@@ -165,12 +170,11 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         // ------------------------------------------------------------ pre-lock coarse scan, four hops at a time
         // (same differential correlator as the single-hop form below, one window per wave, no block barriers
         // inside; used while at least four hops remain before the segment end / end of data)
-        if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0 && pos + 4 * FX_HOP <= n && pos + 3 * FX_HOP < job.stop) {
+        if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n && pos + (WALK_WAVES - 1) * FX_HOP < job.stop) {
             __syncthreads();
-#pragma unroll
-            for (int q = 0; q < 5; q++) L.cw[q * FX_HOP + tid] = xv(x, pos - FX_HOP + q * FX_HOP + tid, floor_, n);
+            for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(x, pos - FX_HOP + i, floor_, n);
             __syncthreads();
-            hops_cheap += 4;
+            hops_cheap += WALK_WAVES;
             {
                 const float2 *w = L.cw + FX_HOP * wave;               // this wave's 512-sample window
                 float2 a[8]; float e = 0.0f; float2 sm = make_float2(0.0f, 0.0f);
@@ -201,27 +205,27 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
                 }
                 wave_argmax(bv, bk);
                 const bool hit = e > 0.0f && bv > 0.06f * e * T->td2sum * (float)FX_NFFT * (float)FX_NFFT;
-                if (lane == 0) L.u[9 + wave] = hit ? bk : 0xFFFFFFFFu;
+                if (lane == 0) L.cand[wave] = hit ? bk : 0xFFFFFFFFu;
             }
             __syncthreads();
             int hw = -1;
 #pragma unroll
-            for (int w = WALK_WAVES - 1; w >= 0; w--) if (L.u[9 + w] != 0xFFFFFFFFu) hw = w;
+            for (int w = WALK_WAVES - 1; w >= 0; w--) if (L.cand[w] != 0xFFFFFFFFu) hw = w;
             if (hw >= 0) {
-                const int64_t p = pos - FX_HOP + (int64_t)FX_HOP * hw + (int64_t)L.u[9 + hw];
+                const int64_t p = pos - FX_HOP + (int64_t)FX_HOP * hw + (int64_t)L.cand[hw];
                 pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
-                L.win[tid] = make_float2(0.0f, 0.0f);
+                if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
             } else {
-                L.win[tid] = L.cw[4 * FX_HOP + tid];                  // last hop becomes the overlap half
-                pos += 4 * FX_HOP; fresh = false;
+                if (lo) L.win[tid] = L.cw[WALK_WAVES * FX_HOP + tid];    // last hop becomes the overlap half
+                pos += WALK_WAVES * FX_HOP; fresh = false;
             }
             __syncthreads();
             WSTAMP(0);
             continue;
         }
 
-        float2 nw = xv(x, pos + tid, floor_, n);
-        L.win[FX_HOP + tid] = nw;
+        float2 nw = lo ? xv(x, pos + tid, floor_, n) : make_float2(0.0f, 0.0f);
+        if (lo) L.win[FX_HOP + tid] = nw;
 
         // ------------------------------------------------------------ pre-lock coarse scan (speculative walkers only)
         // Until a speculative walker has locked onto the chain, nothing it produces is kept, so it may look
@@ -231,9 +235,9 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0) {
             __syncthreads();
             hops_cheap++;
-            float2 d0 = cmulc(L.win[tid + 1], L.win[tid]);
+            float2 d0 = lo ? cmulc(L.win[tid + 1], L.win[tid]) : make_float2(0.0f, 0.0f);
             float2 d1 = (tid < 255) ? cmulc(L.win[tid + 257], L.win[tid + 256]) : make_float2(0.0f, 0.0f);
-            L.X[tid] = d0; L.X[tid + 256] = d1;
+            if (lo) { L.X[tid] = d0; L.X[tid + 256] = d1; }
             // energy of d about its mean: oversampled signals give d a large DC term that is not information
             float ed = block_sum256(cm2(d0) + cm2(d1), L, lane, wave);
             const float2 dsum = block_csum256(cadd(d0, d1), L, lane, wave);
@@ -267,11 +271,11 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
                 // candidate preamble at p: restart the exact detector, fresh, one hop earlier
                 const int64_t p = pos - FX_HOP + (int64_t)cl;
                 pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
-                L.win[tid] = make_float2(0.0f, 0.0f);
+                if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
                 __syncthreads();
                 continue;
             }
-            L.win[tid] = nw;
+            if (lo) L.win[tid] = nw;
             pos += FX_HOP; fresh = false;
             __syncthreads();
             continue;
@@ -331,7 +335,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         WSTAMP(1);
         if (!det) {                                                    // slide the window by one hop
             __syncthreads();
-            L.win[tid] = nw;
+            if (lo) L.win[tid] = nw;
             x2_0 = x2_1; pos += FX_HOP; fresh = false;
             __syncthreads();
             continue;
@@ -344,8 +348,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 
         // ------------------------------------------------------------ ALIGN on x[a0, a0+512)
         __syncthreads();
-        L.win[tid] = xv(x, a0 + tid, floor_, n);
-        L.win[tid + 256] = xv(x, a0 + 256 + tid, floor_, n);
+        for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.win[i] = xv(x, a0 + i, floor_, n);
         __syncthreads();
         if (wave == 0) {
             float2 a[8];
@@ -382,7 +385,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         {
             float2 p = make_float2(0.0f, 0.0f);
             if (tid < FX_S_LEN) p = cmulc(L.win[tid], T->s[tid]);
-            L.P[tid] = p;
+            if (lo) L.P[tid] = p;
         }
         __syncthreads();
         if (wave == 0) {
@@ -436,7 +439,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             // never sees (its hop grid differs).  Ignore it and keep the grid; lock on a strong one.
             if (!locked && !(peak > 0.7f)) {
                 __syncthreads();
-                L.win[tid] = nw; L.win[FX_HOP + tid] = make_float2(0.0f, 0.0f);
+                if (lo) { L.win[tid] = nw; L.win[FX_HOP + tid] = make_float2(0.0f, 0.0f); }
                 x2_0 = x2_1; pos += FX_HOP; fresh = false;
                 __syncthreads();
                 continue;
@@ -447,9 +450,9 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             if (tid == 0) frames[job.frame_base + nfr] = fr;
             nfr++;
             __syncthreads();
-            float2 w = L.win[FX_HOP + tid];
+            float2 w = lo ? L.win[FX_HOP + tid] : make_float2(0.0f, 0.0f);
             __syncthreads();
-            L.win[tid] = w;
+            if (lo) L.win[tid] = w;
             x2_0 = block_sum256(cm2(w), L, lane, wave);
             pos = a0 + FX_NFFT; fresh = false;
             __syncthreads();
@@ -562,7 +565,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             if (tid == 0) frames[job.frame_base + nfr] = fr;
             nfr++;
             __syncthreads();
-            L.win[tid] = xv(x, pos + tid, floor_, n);
+            if (lo) L.win[tid] = nw;
             x2_0 = x2_1; pos += FX_HOP; fresh = false;
             __syncthreads();
             continue;
@@ -576,7 +579,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         // synchroniser reset: fresh detector right after the frame's last symbol
         pos = fr.next; floor_ = fr.next; fresh = true; x2_0 = 0.0f;
         __syncthreads();
-        L.win[tid] = make_float2(0.0f, 0.0f);
+        if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
         __syncthreads();
     }
 
