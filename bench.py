@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 # streams that share a queue serialise.  Eight queues let the walker stream and three payload streams run concurrently.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "3")
+os.environ.setdefault("FXRX_WALK_CUS", "224")      # walker kept off 32 CUs: PLL / decode waves of blocks in flight start at once
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 N_SAMPLES = 20_000_000         # 10 Msym at k = 2 samples/symbol
@@ -89,7 +90,7 @@ def pmc_traffic(kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")

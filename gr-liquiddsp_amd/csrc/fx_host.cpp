@@ -22,7 +22,8 @@
 #include "fx_device.h"
 #include "fx_codec.hpp"
 
-extern "C" __global__ void fx_walk_kernel(const FxWalkJob *, FxWalkResult *, FxFrame *, const FxTables *);
+extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, FxWalkResult *results,
+                                     FxFrame *frames, const FxTables *T);
 extern "C" __global__ void fx_paymf_kernel(const FxPayJob *, const uint32_t *, const uint32_t *, float2 *, const FxTables *);
 extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T);
@@ -110,6 +111,7 @@ struct fxrx_ctx_s {
     hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
     hipStream_t stream_p[4] = { nullptr, nullptr, nullptr, nullptr };   // payload PLL + packet decode, blocks round-robin
     unsigned n_pstreams = 2;
+    int n_cus = 256;
     hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
@@ -187,8 +189,7 @@ int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
 {
     std::memcpy(c->hp_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob));
     HIP_OK(hipMemcpyAsync(c->d_jobs.p + first, c->hp_jobs.p + first, count * sizeof(FxWalkJob), hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(fx_walk_kernel, dim3((unsigned)count), dim3(FX_WALK_THREADS), 0, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables);
-    HIP_OK(hipGetLastError());
+    HIP_OK(fx_launch_walk(c->jobs[first].mode, (unsigned)count, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables));
     return 0;
 }
 
@@ -225,12 +226,14 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(4, std::max(1, std::atoi(e)));
     {
         // The walker fills every CU it may use (8 waves x 256 VGPRs = one register file).  Keeping it off a few CUs
-        // (FXRX_WALK_CUS of the device's CUs, default all but 32) leaves room where the latency-critical PLL / decode
+        // (FXRX_WALK_CUS=<n>; bench.py uses 224 of 256) leaves room where the latency-critical PLL / decode
         // waves of the blocks in flight always find a slot at once.
         hipDeviceProp_t prop; int ncu = 256;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ncu = prop.multiProcessorCount;
-        int want = ncu > 64 ? ncu - 32 : ncu;
+        c->n_cus = ncu;
+        int want = ncu;                                              // default: no mask (best for large batches)
         if (const char *e = std::getenv("FXRX_WALK_CUS")) want = std::atoi(e);
+        if (want > 0 && want < ncu) c->n_cus = want;
         hipError_t err;
         if (want > 0 && want < ncu) {
             std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
@@ -331,9 +334,12 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     uint64_t seg = c->cfg.segment_len;
     if (seg == 0) {
         uint64_t tot = 0; for (unsigned s = 0; s < NS; s++) tot += (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
-        // one walker workgroup (8 waves, the whole register file) per CU, a few CUs left free for the payload
-        // kernels of other blocks in flight
-        seg = tot / (FX_WALK_WAVES == 8 ? 240 : 384);
+        // Walker workgroups resident at once: one per CU for the flex_rx instance (8 waves x 256 VGPRs), two for the
+        // leaner detector-only instance.  Little work: a single round of workgroups with a small margin (the kernel
+        // then lasts as long as its slowest segment).  Lots of work: ~4 rounds so that uneven segments even out.
+        const uint64_t slots = (uint64_t)c->n_cus * (FX_WALK_WAVES == 8 ? (detect ? 2u : 1u) : 2u);
+        if (tot / slots < 131072) seg = tot / (slots - slots / 16);
+        else seg = std::max<uint64_t>(tot / (4 * slots), 65536);
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
     }
     seg = std::max<uint64_t>(seg, 4096);

@@ -127,7 +127,13 @@ __device__ __forceinline__ void decode_header_bytes(WalkLds &L, const FxTables *
     __syncthreads();
 }
 
-extern "C" __global__ __launch_bounds__(WALK_THREADS, 2)
+// MODE is a template parameter so that the detector-only instance (frame_detector_cc) carries none of the
+// header-recovery code or its registers.
+#ifndef FX_DETECT_OCC
+#define FX_DETECT_OCC 4      // waves per SIMD the detector-only instance is compiled for (2 or 4)
+#endif
+template <int MODE>
+__global__ __launch_bounds__(WALK_THREADS, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : 2)
 void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, const FxTables *T)
 {
     __shared__ WalkLds L;
@@ -170,7 +176,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         // ------------------------------------------------------------ pre-lock coarse scan, four hops at a time
         // (same differential correlator as the single-hop form below, one window per wave, no block barriers
         // inside; used while at least four hops remain before the segment end / end of data)
-        if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n && pos + (WALK_WAVES - 1) * FX_HOP < job.stop) {
+        if (!locked && MODE == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n && pos + (WALK_WAVES - 1) * FX_HOP < job.stop) {
             __syncthreads();
             for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(x, pos - FX_HOP + i, floor_, n);
             __syncthreads();
@@ -232,7 +238,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         // for its first preamble any way it likes.  A CFO-blind differential correlator needs 2 FFTs per hop
         // instead of the 50 of the real detector: d[i] = w[i+1] conj(w[i]) against the zero-mean td[k] = s[k+1] conj(s[k]).
         // A hit at lag l re-arms the exact detector (fresh) one hop before the candidate.
-        if (!locked && job.mode == FX_MODE_FLEXRX && exact_left == 0) {
+        if (!locked && MODE == FX_MODE_FLEXRX && exact_left == 0) {
             __syncthreads();
             hops_cheap++;
             float2 d0 = lo ? cmulc(L.win[tid + 1], L.win[tid]) : make_float2(0.0f, 0.0f);
@@ -434,7 +440,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 #pragma unroll
         for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = 0;
 
-        if (job.mode == FX_MODE_DETECT) {
+        if (MODE == FX_MODE_DETECT) {
             // Speculative walker not yet locked: a weak peak may be a false alarm the sequential chain
             // never sees (its hop grid differs).  Ignore it and keep the grid; lock on a strong one.
             if (!locked && !(peak > 0.7f)) {
@@ -595,6 +601,14 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 #endif
         results[blockIdx.x] = r;
     }
+}
+
+extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, FxWalkResult *results,
+                                     FxFrame *frames, const FxTables *T)
+{
+    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL(fx_walk_kernel<FX_MODE_DETECT>, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, frames, T);
+    else hipLaunchKernelGGL(fx_walk_kernel<FX_MODE_FLEXRX>, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, frames, T);
+    return hipGetLastError();
 }
 
 // ===================================================================== payload: mix + polyphase MF
