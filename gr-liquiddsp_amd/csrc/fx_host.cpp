@@ -98,7 +98,7 @@ struct Slot {
     std::vector<Out> out;
     uint64_t n_syms = 0;
     fxrx_timing timing{};
-    hipEvent_t ev_mf0 = nullptr, ev_mf1 = nullptr, ev_pll1 = nullptr, ev_dec1 = nullptr, ev_done = nullptr;
+    hipEvent_t ev_mf0 = nullptr, ev_mf1 = nullptr, ev_pll0 = nullptr, ev_pll1 = nullptr, ev_dec0 = nullptr, ev_dec1 = nullptr, ev_done = nullptr;
     hipStream_t stream_p = nullptr, stream_d = nullptr;   // borrowed from the context (see fxrx_ctx_s)
     bool busy = false;
 };
@@ -205,7 +205,7 @@ int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess
 static int make_slot(fxrx_ctx_s *c)
 {
     std::unique_ptr<Slot> s(new Slot);
-    hipEvent_t *ev[5] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll1, &s->ev_dec1, &s->ev_done };
+    hipEvent_t *ev[7] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll0, &s->ev_pll1, &s->ev_dec0, &s->ev_dec1, &s->ev_done };
     for (auto e : ev) HIP_OK(hipEventCreate(e));
     s->stream_p = c->stream_p[c->slots.size() % c->n_pstreams]; s->stream_d = s->stream_p;
     c->slots.push_back(std::move(s));
@@ -263,7 +263,7 @@ void fxrx_destroy(fxrx_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     sync_all(c);
     for (auto &s : c->slots) {
-        hipEvent_t ev[5] = { s->ev_mf0, s->ev_mf1, s->ev_pll1, s->ev_dec1, s->ev_done };
+        hipEvent_t ev[7] = { s->ev_mf0, s->ev_mf1, s->ev_pll0, s->ev_pll1, s->ev_dec0, s->ev_dec1, s->ev_done };
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
     }
     if (c->ev_w0) (void)hipEventDestroy(c->ev_w0);
@@ -537,6 +537,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         HIP_OK(hipEventRecord(sl.ev_mf1, c->stream));
         // P: payload PLL
         HIP_OK(hipStreamWaitEvent(sl.stream_p, sl.ev_mf1, 0));
+        HIP_OK(hipEventRecord(sl.ev_pll0, sl.stream_p));            // reached once the MF is done: kernel start, not queueing
         // stagger concurrent blocks' PLL grids over different CUs (see the kernel): slot k skips k * (grid rounded to 32)
         const unsigned pll_wgs = (unsigned)((NP + 63) / 64);
         const unsigned wg_skip = pll_wgs <= 128 ? c->head * ((pll_wgs + 31u) & ~31u) : 0u;
@@ -546,6 +547,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         HIP_OK(hipEventRecord(sl.ev_pll1, sl.stream_p));
         // D: packet decode, results home
         HIP_OK(hipStreamWaitEvent(sl.stream_d, sl.ev_pll1, 0));
+        HIP_OK(hipEventRecord(sl.ev_dec0, sl.stream_d));
         hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, sl.stream_d,
                            sl.d_pjobs.p, sl.d_hard.p, c->d_perm.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables);
         HIP_OK(hipGetLastError());
@@ -597,8 +599,8 @@ int fxrx_collect(fxrx_ctx *c)
     if (!sl.pjobs.empty()) {
         float ms = 0;
         (void)hipEventElapsedTime(&ms, sl.ev_mf0, sl.ev_mf1); sl.timing.paymf_ms = ms;
-        (void)hipEventElapsedTime(&ms, sl.ev_mf1, sl.ev_pll1); sl.timing.paypll_ms = ms;     // includes queueing behind earlier blocks when pipelined
-        (void)hipEventElapsedTime(&ms, sl.ev_pll1, sl.ev_dec1); sl.timing.paydec_ms = ms;
+        (void)hipEventElapsedTime(&ms, sl.ev_pll0, sl.ev_pll1); sl.timing.paypll_ms = ms;
+        (void)hipEventElapsedTime(&ms, sl.ev_dec0, sl.ev_dec1); sl.timing.paydec_ms = ms;
     }
     sl.timing.total_ms = sl.timing.walk_ms + sl.timing.paymf_ms + sl.timing.paypll_ms + sl.timing.paydec_ms;
     sl.busy = false; c->last = &sl;
