@@ -105,11 +105,19 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU path to measure)")
+    # BENCH_FORCE_DEVICE / BENCH_DIST_BACKEND exist only to rehearse the N>1 code path on a one-GPU box (all ranks on
+    # device 0 over gloo); the driver's multi-GPU run uses one GPU per rank over RCCL ("nccl").
+    if "BENCH_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["BENCH_FORCE_DEVICE"])
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     fx = importlib.import_module("gr-liquiddsp_amd")
 
     (sid,) = shard_streams(world, rank, world)            # one stream per rank
@@ -170,7 +178,7 @@ def main():
     torch.cuda.synchronize()
     if world > 1: dist.barrier()
     dt = time.perf_counter() - t0
-    dt = reduce_max_time(dt, dist if world > 1 else None, dev)
+    dt = reduce_max_time(dt, dist if world > 1 else None, dev if backend == "nccl" else None)
     ok = check(nres)
 
     if rank == 0:

@@ -272,3 +272,57 @@ def test_cpp_block_shells_loopback(fx, tmp_path):
                            "-L" + lib, "-lfxrx", "-Wl,-rpath," + lib])
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
+def test_dropin_qdetector_and_msequence(fx, oracle):
+    """The per-sample liquid names frame_detector_cc calls (lib/frame_detector_cc_impl.cc:47-55,63,77): every detection
+    is reported exactly once with the oracle's estimates; the returned pointer holds the 512 aligned samples."""
+    L = fx.lib()
+    ms = L.msequence_create(7, 0x0089, 1)
+    pn = np.zeros(64, np.complex64)
+    for i in range(64):
+        re = np.sqrt(0.5) if L.msequence_advance(ms) else -np.sqrt(0.5)
+        im = np.sqrt(0.5) if L.msequence_advance(ms) else -np.sqrt(0.5)
+        pn[i] = re + 1j * im
+    L.msequence_destroy(ms)
+    assert L.qdetector_cccf_create_linear(pn.ctypes.data, 63, 7, 2, 7, C.c_float(0.3)) is None      # not the flexframe preamble
+    q = L.qdetector_cccf_create_linear(pn.ctypes.data, 64, 7, 2, 7, C.c_float(0.3))
+    assert q
+    L.qdetector_cccf_set_threshold(q, 0.45)
+    assert L.qdetector_cccf_get_buf_len(q) == 512
+    x, inj = fx.synth_stream(140_000, stream_id=81, payload_len=200)
+    x = np.concatenate([x, np.zeros(70_000, np.complex64)])           # flush the block queue (64 Ki samples)
+    od = oracle.Detector(0.45).run(x)
+    got = []
+    xs = x.view(np.float32).reshape(-1, 2)
+    for i in range(len(x)):
+        p = L.qdetector_cccf_execute(q, fx._ffi.FxComplex(float(xs[i, 0]), float(xs[i, 1])))
+        if p:
+            win = np.frombuffer(C.cast(p, C.POINTER(C.c_float * 1024)).contents, np.complex64).copy()
+            got.append((L.qdetector_cccf_get_tau(q), L.qdetector_cccf_get_gamma(q), L.qdetector_cccf_get_dphi(q),
+                        L.qdetector_cccf_get_phi(q), win))
+    L.qdetector_cccf_destroy(q)
+    od = [d for d in od if d["pos"] + 512 <= 131072]                  # detections inside the blocks that were run
+    assert len(got) >= len(od) >= 8
+    for d, g in zip(od, got):
+        assert abs(d["tau"] - g[0]) < 1e-5 and abs(d["gamma"] - g[1]) < 1e-5 and abs(d["dphi"] - g[2]) < 1e-5 and abs(d["phi"] - g[3]) < 1e-5
+        lo = max(d["pos"], 0)
+        assert np.array_equal(g[4][lo - d["pos"]:], x[lo:d["pos"] + 512])
+
+
+def test_pipelined_multi_stream_detector_mode(fx, oracle):
+    xs = [fx.synth_stream(200_000, stream_id=90 + i, payload_len=300)[0] for i in range(3)]
+    ctx = fx.RxContext(3, mode=fx.MODE_DETECTOR, threshold=0.45)
+    ctx.set_depth(2)
+    got = []
+    for lo in range(0, 200_000, 50_000):
+        blk = [x[lo:lo + 50_000] for x in xs]
+        ctx.submit_raw([b.ctypes.data for b in blk], [len(b) for b in blk], False)
+        if lo:
+            got += ctx.results(ctx.collect_raw())
+    got += ctx.results(ctx.collect_raw())
+    for s, x in enumerate(xs):
+        od = oracle.Detector(0.45).run(x)
+        mine = [g for g in got if g["stream"] == s]
+        assert [d["pos"] for d in od if d["pos"] + 512 <= 200_000] == [g["start"] for g in mine][:len([d for d in od if d["pos"] + 512 <= 200_000])]
+        assert len(mine) >= 10
