@@ -6,6 +6,7 @@
 // Everything here is setup / transmit-side work on the host.  The receive arithmetic itself lives in
 // fx_kernels.hip and has no host implementation in this library.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -185,9 +186,23 @@ struct BlockCodes {
     uint8_t sd22_col[16], sd39_col[32];
     uint8_t h74_enc[16], h74_dec[128]; uint16_t h128_enc[256]; uint8_t h128_dec[4096];
     uint32_t gol_enc[4096], gol_err[4096];
+    uint8_t rs_exp[512], rs_log[256], rs_gen[33];      // GF(2^8)/0x11d tables, RS(255,223) generator (roots alpha^1..alpha^32)
+    uint8_t gmul(uint8_t a, uint8_t b) const { return (a && b) ? rs_exp[rs_log[a] + rs_log[b]] : 0; }
     unsigned gol_syndrome(uint32_t cw) const { return (unsigned)((gol_enc[(cw >> 12) & 0xfff] ^ cw) & 0xfff); }
     BlockCodes()
     {
+        {   // GF(256) and the Reed-Solomon generator polynomial
+            unsigned x = 1;
+            for (unsigned i = 0; i < 255; i++) { rs_exp[i] = (uint8_t)x; rs_log[x] = (uint8_t)i; x <<= 1; if (x & 0x100) x ^= 0x11d; }
+            for (unsigned i = 255; i < 512; i++) rs_exp[i] = rs_exp[i - 255];
+            rs_log[0] = 0;
+            std::memset(rs_gen, 0, sizeof rs_gen); rs_gen[0] = 1;
+            for (unsigned i = 1; i <= 32; i++) {
+                const uint8_t root = rs_exp[i];
+                for (int k = (int)i; k > 0; k--) rs_gen[k] = (uint8_t)(rs_gen[k - 1] ^ gmul(rs_gen[k], root));
+                rs_gen[0] = gmul(rs_gen[0], root);
+            }
+        }
         {   // Hsiao columns for the two short SECDED codes: the first 16 / 32 weight-3 words of 6 / 7 bits
             unsigned k = 0;
             for (unsigned v = 1; v < 64 && k < 16; v++) if (__builtin_popcount(v) == 3) sd22_col[k++] = (uint8_t)v;
@@ -284,14 +299,16 @@ inline bool fec_supported(unsigned fs)
 {
     unsigned k, n;
     return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || fs == FX_FEC_SECDED2216 ||
-           fs == FX_FEC_SECDED3932 || blk_spec(fs, k, n) || conv_period(fs) != 0;
+           fs == FX_FEC_SECDED3932 || fs == FX_FEC_RS_M8 || blk_spec(fs, k, n) || conv_period(fs) != 0;
 }
+inline void rs_dims(unsigned n, unsigned &nb, unsigned &dl) { nb = (n + 222) / 223; if (nb == 0) nb = 1; dl = (n + nb - 1) / nb; }
 inline unsigned fec_enc_len(unsigned fs, unsigned n)
 {
     int p = conv_period(fs);
     if (p) { unsigned T = 8 * n + 6; unsigned bits = p == 1 ? 2 * T : T + (T + (unsigned)p - 1) / (unsigned)p; return (bits + 7) / 8; }
     unsigned bk, bn;
     if (blk_spec(fs, bk, bn)) { unsigned nb = (8 * n + bk - 1) / bk; return (nb * bn + 7) / 8; }
+    if (fs == FX_FEC_RS_M8) { unsigned nb, dl; rs_dims(n, nb, dl); return nb * (dl + 32); }
     if (fs == FX_FEC_SECDED2216) return 3 * (n / 2) + ((n % 2) ? (n % 2) + 1 : 0);
     if (fs == FX_FEC_SECDED3932) return 5 * (n / 4) + ((n % 4) ? (n % 4) + 1 : 0);
     if (fs == FX_FEC_HAMMING84) return 2 * n;
@@ -324,6 +341,23 @@ inline void fec_encode(unsigned fs, unsigned n, const uint8_t *dec, uint8_t *enc
             for (unsigned i = 0; i < bk; i++) { unsigned q = j * bk + i; d = (d << 1) | (q < 8 * n ? (dec[q >> 3] >> (7 - (q & 7))) & 1u : 0u); }
             const uint32_t cw = fs == FX_FEC_HAMMING74 ? bc.h74_enc[d] : fs == FX_FEC_HAMMING128 ? bc.h128_enc[d] : bc.gol_enc[d];
             for (unsigned i = 0; i < bn; i++) { unsigned q = j * bn + i; if ((cw >> (bn - 1 - i)) & 1u) enc[q >> 3] |= (uint8_t)(0x80u >> (q & 7)); }
+        }
+        return;
+    }
+    if (fs == FX_FEC_RS_M8) {        // RS(255,223), message cut into equal shortened blocks, 32 parity bytes each
+        unsigned nb, dl; rs_dims(n, nb, dl);
+        for (unsigned b = 0; b < nb; b++) {
+            uint8_t d[223] = { 0 }, par[32] = { 0 };
+            const unsigned off = b * dl, len = off < n ? std::min(n - off, dl) : 0;
+            std::memcpy(d, dec + off, len);
+            for (unsigned i = 0; i < dl; i++) {
+                const uint8_t fb = (uint8_t)(d[i] ^ par[31]);
+                for (int k = 31; k > 0; k--) par[k] = (uint8_t)(par[k - 1] ^ bc.gmul(fb, bc.rs_gen[k]));
+                par[0] = bc.gmul(fb, bc.rs_gen[0]);
+            }
+            uint8_t *o = enc + b * (dl + 32);
+            std::memcpy(o, d, dl);
+            for (unsigned k = 0; k < 32; k++) o[dl + k] = par[31 - k];
         }
         return;
     }

@@ -27,6 +27,7 @@ struct FxTables {
     uint8_t  h74dec[128];
     uint8_t  h128dec[4096];
     uint32_t golenc[4096], golerr[4096];   // Golay(24,12): codeword of a 12-bit word, error pattern of a syndrome
+    uint8_t  rsexp[512], rslog[256];       // GF(2^8)/0x11d for Reed-Solomon RS(255,223)
 };
 
 #define FX_DEV __device__ __forceinline__
@@ -305,7 +306,7 @@ FX_DEV bool fec_supported(unsigned fs)
 {
     unsigned k, n;
     return fs == FX_FEC_NONE || fs == FX_FEC_HAMMING84 || fs == FX_FEC_SECDED7264 || fs == FX_FEC_SECDED2216 ||
-           fs == FX_FEC_SECDED3932 || blk_spec(fs, k, n) || conv_p(fs) != 0;
+           fs == FX_FEC_SECDED3932 || fs == FX_FEC_RS_M8 || blk_spec(fs, k, n) || conv_p(fs) != 0;
 }
 FX_DEV unsigned fec_enc_len(unsigned fs, unsigned n)
 {
@@ -317,6 +318,7 @@ FX_DEV unsigned fec_enc_len(unsigned fs, unsigned n)
     }
     unsigned bk, bn;
     if (blk_spec(fs, bk, bn)) { unsigned nb = (8 * n + bk - 1) / bk; return (nb * bn + 7) / 8; }
+    if (fs == FX_FEC_RS_M8) { unsigned nb = (n + 222) / 223; if (nb == 0) nb = 1; const unsigned dl = (n + nb - 1) / nb; return nb * (dl + 32); }
     if (fs == FX_FEC_SECDED2216) return 3 * (n / 2) + ((n % 2) ? (n % 2) + 1 : 0);
     if (fs == FX_FEC_SECDED3932) return 5 * (n / 4) + ((n % 4) ? (n % 4) + 1 : 0);
     if (fs == FX_FEC_HAMMING84) return 2 * n;

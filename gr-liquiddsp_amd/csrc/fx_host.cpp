@@ -27,8 +27,9 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t 
 extern "C" __global__ void fx_paymf_kernel(const FxPayJob *, const uint32_t *, const uint32_t *, float2 *, const FxTables *);
 extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T);
-extern "C" __global__ void fx_paydec_kernel(const FxPayJob *, const uint8_t *, const uint32_t *, uint8_t *, uint8_t *,
-                                            unsigned long long *, uint8_t *, FxPayResult *, const FxTables *);
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
+                                       const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
+                                       FxPayResult *res, const FxTables *T);
 
 namespace {
 
@@ -91,7 +92,7 @@ struct Out { fxrx_frame f; int pjob; };
 // block n, the packet decode of block n-1 and the walk of block n+1 can run concurrently on three streams.
 struct Slot {
     std::vector<FxPayJob> pjobs; std::vector<uint32_t> blk_job, blk_c0, pll_idx;
-    DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0, d_pll_idx;
+    DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0, d_pll_idx, d_dec_idx;
     DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_out; DevBuf<unsigned long long> d_dw;
     DevBuf<FxPayResult> d_pres; PinBuf<FxPayResult> h_pres; PinBuf<uint8_t> h_out; PinBuf<float2> h_framesyms;
     PinBuf<FxPayJob> hp_pjobs; PinBuf<uint32_t> hp_idx;          // pinned staging: H2D really is asynchronous
@@ -163,6 +164,7 @@ int upload_tables(fxrx_ctx_s *c)
     std::memcpy(t->sd22col, B.sd22_col, 16); std::memcpy(t->sd39col, B.sd39_col, 32);
     std::memcpy(t->h74dec, B.h74_dec, 128); std::memcpy(t->h128dec, B.h128_dec, 4096);
     std::memcpy(t->golenc, B.gol_enc, sizeof B.gol_enc); std::memcpy(t->golerr, B.gol_err, sizeof B.gol_err);
+    std::memcpy(t->rsexp, B.rs_exp, 512); std::memcpy(t->rslog, B.rs_log, 256);
     HIP_OK(hipMalloc((void **)&c->d_tables, sizeof(FxTables)));
     HIP_OK(hipMemcpy(c->d_tables, t.get(), sizeof(FxTables), hipMemcpyHostToDevice));
     return 0;
@@ -511,7 +513,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         }
         const size_t NB = sl.blk_job.size();
         if (sl.d_pjobs.reserve(NP) || sl.hp_pjobs.reserve(NP) || sl.d_blk_job.reserve(NB) || sl.d_blk_c0.reserve(NB) ||
-            sl.d_pll_idx.reserve(NP) || sl.hp_idx.reserve(2 * NB + NP) ||
+            sl.d_pll_idx.reserve(NP) || sl.d_dec_idx.reserve(NP) || sl.hp_idx.reserve(2 * NB + 2 * NP) ||
             sl.d_symraw.reserve(sym_total + 8) || sl.d_framesyms.reserve(sym_total + 8) || sl.d_hard.reserve(sym_total + 64) ||
             sl.d_bufA.reserve(byte_total) || sl.d_bufB.reserve(byte_total) || sl.d_dw.reserve(dw_total) ||
             sl.d_out.reserve(out_total + 16) || sl.d_pres.reserve(NP) || sl.h_pres.reserve(NP) || sl.h_out.reserve(out_total + 16)) return FXRX_ERR_HIP;
@@ -525,11 +527,19 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         std::memcpy(sl.hp_idx.p, sl.blk_job.data(), NB * sizeof(uint32_t));
         std::memcpy(sl.hp_idx.p + NB, sl.blk_c0.data(), NB * sizeof(uint32_t));
         std::memcpy(sl.hp_idx.p + 2 * NB, sl.pll_idx.data(), NP * sizeof(uint32_t));
+        // decode grids: frames without / with a Reed-Solomon stage (the latter use a heavier kernel instance)
+        size_t n_plain = 0, n_rs = 0;
+        {
+            uint32_t *di = sl.hp_idx.p + 2 * NB + NP;
+            for (size_t i = 0; i < NP; i++) if (sl.pjobs[i].fec0 != FX_FEC_RS_M8 && sl.pjobs[i].fec1 != FX_FEC_RS_M8) di[n_plain++] = (uint32_t)i;
+            for (size_t i = 0; i < NP; i++) if (sl.pjobs[i].fec0 == FX_FEC_RS_M8 || sl.pjobs[i].fec1 == FX_FEC_RS_M8) di[n_plain + n_rs++] = (uint32_t)i;
+        }
         // W: payload matched filter (the only payload stage that reads the IQ)
         HIP_OK(hipMemcpyAsync(sl.d_pjobs.p, sl.hp_pjobs.p, NP * sizeof(FxPayJob), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(sl.d_blk_job.p, sl.hp_idx.p, NB * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(sl.d_blk_c0.p, sl.hp_idx.p + NB, NB * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipMemcpyAsync(sl.d_pll_idx.p, sl.hp_idx.p + 2 * NB, NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_OK(hipMemcpyAsync(sl.d_dec_idx.p, sl.hp_idx.p + 2 * NB + NP, NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_OK(hipEventRecord(sl.ev_mf0, c->stream));
         hipLaunchKernelGGL(fx_paymf_kernel, dim3((unsigned)NB), dim3(256), 0, c->stream,
                            sl.d_pjobs.p, sl.d_blk_job.p, sl.d_blk_c0.p, sl.d_symraw.p, c->d_tables);
@@ -548,9 +558,10 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         // D: packet decode, results home
         HIP_OK(hipStreamWaitEvent(sl.stream_d, sl.ev_pll1, 0));
         HIP_OK(hipEventRecord(sl.ev_dec0, sl.stream_d));
-        hipLaunchKernelGGL(fx_paydec_kernel, dim3((unsigned)NP), dim3(64), 0, sl.stream_d,
-                           sl.d_pjobs.p, sl.d_hard.p, c->d_perm.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables);
-        HIP_OK(hipGetLastError());
+        if (n_plain) HIP_OK(fx_launch_paydec(0, (unsigned)n_plain, sl.stream_d, sl.d_pjobs.p, sl.d_dec_idx.p, sl.d_hard.p, c->d_perm.p,
+                                            sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables));
+        if (n_rs) HIP_OK(fx_launch_paydec(1, (unsigned)n_rs, sl.stream_d, sl.d_pjobs.p, sl.d_dec_idx.p + n_plain, sl.d_hard.p, c->d_perm.p,
+                                         sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev_dec1, sl.stream_d));
         HIP_OK(hipMemcpyAsync(sl.h_pres.p, sl.d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, sl.stream_d));
         HIP_OK(hipMemcpyAsync(sl.h_out.p, sl.d_out.p, out_total, hipMemcpyDeviceToHost, sl.stream_d));

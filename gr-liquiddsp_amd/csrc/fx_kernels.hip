@@ -795,6 +795,54 @@ __device__ __forceinline__ void secded_decode(const uint8_t *col, uint32_t nd, u
     }
 }
 
+// Reed-Solomon RS(255,223) block of N = dl + 32 bytes, corrected in place in `r` (a lane-private copy); syndromes,
+// Berlekamp-Massey, Chien search, Forney -- the same steps, in the same order, as the CPU side (more than 16 byte
+// errors: left as received)
+__device__ void rs_decode_block(uint8_t *r, unsigned N, const FxTables *T)
+{
+    const uint8_t *ex = T->rsexp, *lg = T->rslog;
+    auto gm = [&](uint8_t a, uint8_t b) -> uint8_t { return (a && b) ? ex[lg[a] + lg[b]] : (uint8_t)0; };
+    auto gd = [&](uint8_t a, uint8_t b) -> uint8_t { return a ? ex[lg[a] + 255 - lg[b]] : (uint8_t)0; };
+    uint8_t S[32]; unsigned nz = 0;
+    for (unsigned i = 0; i < 32; i++) {
+        const uint8_t a = ex[i + 1]; uint8_t sy = 0;
+        for (unsigned j = 0; j < N; j++) sy = (uint8_t)(gm(sy, a) ^ r[j]);
+        S[i] = sy; nz |= sy;
+    }
+    if (!nz) return;
+    uint8_t Lm[33], B[33], Tm[33];
+    for (int i = 0; i < 33; i++) { Lm[i] = 0; B[i] = 0; }
+    Lm[0] = B[0] = 1;
+    unsigned L = 0, m = 1; uint8_t b = 1;
+    for (unsigned k = 0; k < 32; k++) {
+        uint8_t d = S[k];
+        for (unsigned i = 1; i <= L; i++) d ^= gm(Lm[i], S[k - i]);
+        if (d == 0) { m++; continue; }
+        for (int i = 0; i < 33; i++) Tm[i] = Lm[i];
+        const uint8_t coef = gd(d, b);
+        for (unsigned i = 0; i + m <= 32; i++) Lm[i + m] ^= gm(coef, B[i]);
+        if (2 * L <= k) { L = k + 1 - L; for (int i = 0; i < 33; i++) B[i] = Tm[i]; b = d; m = 1; } else m++;
+    }
+    if (L > 16) return;
+    uint8_t Om[32];
+    for (unsigned i = 0; i < 32; i++) { uint8_t v = 0; for (unsigned j = 0; j <= i && j <= L; j++) v ^= gm(Lm[j], S[i - j]); Om[i] = v; }
+    unsigned pos[16], np = 0; uint8_t val[16];
+    for (unsigned j = 0; j < N; j++) {
+        const unsigned e = (N - 1 - j) % 255, inv = (255 - e) % 255;
+        uint8_t v = 0;
+        for (unsigned i = 0; i <= L; i++) v ^= gm(Lm[i], ex[(inv * i) % 255]);
+        if (v) continue;
+        if (np == 16) return;
+        uint8_t num = 0, den = 0;
+        for (unsigned i = 0; i < 32; i++) num ^= gm(Om[i], ex[(inv * i) % 255]);
+        for (unsigned i = 1; i <= L; i += 2) den ^= gm(Lm[i], ex[(inv * (i - 1)) % 255]);
+        if (den == 0) return;
+        pos[np] = j; val[np] = gd(num, den); np++;
+    }
+    if (np != L) return;
+    for (unsigned i = 0; i < np; i++) r[pos[i]] ^= val[i];
+}
+
 __device__ __forceinline__ unsigned take_bits(const uint8_t *b, uint32_t nbytes, uint32_t pos, unsigned nbits)
 {
     unsigned v = 0;
@@ -802,6 +850,7 @@ __device__ __forceinline__ unsigned take_bits(const uint8_t *b, uint32_t nbytes,
     return v;
 }
 
+template <bool WITH_RS>
 __device__ __forceinline__ void block_fec_decode(unsigned fs, uint32_t n, const uint8_t *enc, uint8_t *dec, const FxTables *T, int lane)
 {
     unsigned bk, bn;
@@ -814,6 +863,16 @@ __device__ __forceinline__ void block_fec_decode(unsigned fs, uint32_t n, const 
         secded_decode(T->sd39col, 4, n, enc, dec, lane);
     } else if (fs == FX_FEC_SECDED2216) {
         secded_decode(T->sd22col, 2, n, enc, dec, lane);
+    } else if (WITH_RS && fs == FX_FEC_RS_M8) {
+        // one lane per 255-byte block; the block is corrected in place in the (mutable) encoded buffer
+        uint32_t nb = (n + 222) / 223; if (nb == 0) nb = 1;
+        const uint32_t dl = (n + nb - 1) / nb;
+        for (uint32_t blk = lane; blk < nb; blk += DEC_THREADS) {
+            uint8_t *r = const_cast<uint8_t *>(enc) + (size_t)blk * (dl + 32);
+            rs_decode_block(r, dl + 32, T);
+            const uint32_t off = blk * dl, len = off < n ? min(n - off, dl) : 0u;
+            for (uint32_t j = 0; j < len; j++) dec[off + j] = r[j];
+        }
     } else if (blk_spec(fs, bk, bn)) {
         // bit-packed codewords: decode whole output bytes per lane (lcm(k,8)/k codewords make lcm(k,8)/8 bytes)
         const uint32_t el = fec_enc_len(fs, n);
@@ -1092,19 +1151,23 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 }
 
 #ifdef FX_STAMPS
-#define FX_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) res[blockIdx.x].stamp[i] = (uint32_t)(t_ - t_prev); t_prev = t_; } while (0)
+#define FX_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) res[jf].stamp[i] = (uint32_t)(t_ - t_prev); t_prev = t_; } while (0)
 #define FX_STAMP_INIT unsigned long long t_prev = __builtin_readcyclecounter()
 #else
 #define FX_STAMP(i) do { } while (0)
 #define FX_STAMP_INIT do { } while (0)
 #endif
 
-extern "C" __global__ __launch_bounds__(DEC_THREADS)
-void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB,
+// WITH_RS: the Reed-Solomon decoder keeps ~150 bytes of per-lane state; frames that use it go through their own
+// instance so that every other frame keeps the lean (39-VGPR, 8 waves/SIMD) one.  job_idx lists this grid's frames.
+template <bool WITH_RS>
+__global__ __launch_bounds__(DEC_THREADS)
+void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB,
                       unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
 {
     __builtin_amdgcn_s_setprio(2);
-    FxPayJob job = jobs[blockIdx.x];
+    const uint32_t jf = job_idx[blockIdx.x];
+    FxPayJob job = jobs[jf];
     // one wave per frame: pin the loop bounds into SGPRs so that every loop below is scalar-controlled
     job.l0 = __builtin_amdgcn_readfirstlane(job.l0); job.l1 = __builtin_amdgcn_readfirstlane(job.l1);
     job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
@@ -1135,16 +1198,16 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
     const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
     if (pc1 == 1) viterbi27<false>(1, job.l0, B, A, dw_arena + job.dw_off, B, lane, nullptr);
     else if (pc1) viterbi27<true>(pc1, job.l0, B, A, dw_arena + job.dw_off, B, lane, nullptr);
-    else block_fec_decode(job.fec1, job.l0, B, A, T, lane);
+    else block_fec_decode<WITH_RS>(job.fec1, job.l0, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(2);
     // 3. inner plan (fec0): de-interleave l0, decode -> k bytes
     permute_bits(A, B, perm_arena + job.perm0_off, job.l0, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(3);
-    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[blockIdx.x].stamp[6]);
-    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[blockIdx.x].stamp[6]);
-    else block_fec_decode(job.fec0, job.k, B, A, T, lane);
+    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[jf].stamp[6]);
+    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[jf].stamp[6]);
+    else block_fec_decode<WITH_RS>(job.fec0, job.k, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(4);
     // 4. de-whiten, CRC, copy out
@@ -1170,9 +1233,18 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint8_t *hard, const uint32_t 
         default: key = 0; break;
         }
         if (lane == 0) {
-            res[blockIdx.x].payload_valid = (key == rx) ? 1u : 0u;
-            res[blockIdx.x].status = status;
+            res[jf].payload_valid = (key == rx) ? 1u : 0u;
+            res[jf].status = status;
         }
     }
     FX_STAMP(5);
+}
+
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
+                                       const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
+                                       FxPayResult *res, const FxTables *T)
+{
+    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, job_idx, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
+    else hipLaunchKernelGGL(fx_paydec_kernel<false>, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, job_idx, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
+    return hipGetLastError();
 }

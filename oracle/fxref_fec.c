@@ -13,7 +13,8 @@
  *    register for the 8/16/24-bit keys.
  *  - Hamming(7,4)/(8,4)/(12,8), Golay(24,12) and SECDED(22,16)/(39,32)/(72,64) use textbook constructions
  *    (systematic / positional Hamming, cyclic Golay with g = 0xC75 + overall parity, Hsiao odd-weight columns),
- *    not liquid's literal generator tables, which are not recalled.  Reed-Solomon (RS_M8) is not built.
+ *    not liquid's literal generator tables, which are not recalled.  Reed-Solomon RS_M8 = RS(255,223), GF(2^8)/0x11d,
+ *    roots alpha^1..alpha^32, shortened per block as liquid's fec_rs does.
  *  - Viterbi: K=7 (0x6d,0x4f), hard decisions, Hamming branch metric, punctured positions cost 0,
  *    ties keep the lower predecessor, traceback from state 0.  libfec's 8-bit soft metric on
  *    0/255 inputs selects the same path except on exact metric ties.
@@ -298,6 +299,106 @@ static void blk_decode(int fs, unsigned dec_len, const uint8_t *enc, uint8_t *de
     }
 }
 
+/* ---------------------------------------------------------------- Reed-Solomon RS(255,223) over GF(2^8), shortened per block
+ * [RECALLED liquid fec_rs.c + libfec init_rs_char(8, 0x11d, fcr=1, prim=1, nroots=32)]: the message is cut into
+ * nb = ceil(n/223) blocks of dl = ceil(n/nb) bytes (last one zero padded), each followed by 32 parity bytes.
+ * Decoder: syndromes, Berlekamp-Massey, Chien search, Forney; a block with more than 16 byte errors is left as is. */
+static uint8_t rs_exp[512], rs_log[256], rs_gen[33];
+static int rs_ready = 0;
+static inline uint8_t gmul(uint8_t a, uint8_t b) { return (a && b) ? rs_exp[rs_log[a] + rs_log[b]] : 0; }
+static inline uint8_t gdiv(uint8_t a, uint8_t b) { return a ? rs_exp[rs_log[a] + 255 - rs_log[b]] : 0; }
+static void rs_init(void)
+{
+    if (rs_ready) return;
+    unsigned x = 1;
+    for (unsigned i = 0; i < 255; i++) { rs_exp[i] = (uint8_t)x; rs_log[x] = (uint8_t)i; x <<= 1; if (x & 0x100) x ^= 0x11d; }
+    for (unsigned i = 255; i < 512; i++) rs_exp[i] = rs_exp[i - 255];
+    rs_log[0] = 0;
+    memset(rs_gen, 0, sizeof rs_gen); rs_gen[0] = 1;                     /* g(x) = prod (x - alpha^i), i = 1..32; rs_gen[k] = coeff of x^k */
+    for (unsigned i = 1; i <= 32; i++) {
+        uint8_t root = rs_exp[i];
+        for (int k = (int)i; k > 0; k--) rs_gen[k] = (uint8_t)(rs_gen[k - 1] ^ gmul(rs_gen[k], root));
+        rs_gen[0] = gmul(rs_gen[0], root);
+    }
+    rs_ready = 1;
+}
+static void rs_dims(unsigned n, unsigned *nb, unsigned *dl)
+{
+    *nb = (n + 222) / 223; if (*nb == 0) *nb = 1;
+    *dl = (n + *nb - 1) / *nb;
+}
+static void rs_encode_block(const uint8_t *d, unsigned dl, uint8_t *out /* dl + 32 */)
+{
+    uint8_t par[32]; memset(par, 0, 32);                                 /* par[31] is the highest-order remainder term */
+    for (unsigned i = 0; i < dl; i++) {
+        uint8_t fb = (uint8_t)(d[i] ^ par[31]);
+        for (int k = 31; k > 0; k--) par[k] = (uint8_t)(par[k - 1] ^ gmul(fb, rs_gen[k]));
+        par[0] = gmul(fb, rs_gen[0]);
+    }
+    memcpy(out, d, dl);
+    for (unsigned k = 0; k < 32; k++) out[dl + k] = par[31 - k];
+}
+static void rs_decode_block(uint8_t *r, unsigned N /* dl + 32 */)
+{
+    uint8_t S[32]; int nz = 0;
+    for (unsigned i = 0; i < 32; i++) {
+        uint8_t a = rs_exp[i + 1], s = 0;
+        for (unsigned j = 0; j < N; j++) s = (uint8_t)(gmul(s, a) ^ r[j]);
+        S[i] = s; nz |= s;
+    }
+    if (!nz) return;
+    uint8_t L_[33], B[33], T[33]; memset(L_, 0, 33); memset(B, 0, 33); L_[0] = B[0] = 1;
+    unsigned L = 0, m = 1; uint8_t b = 1;
+    for (unsigned k = 0; k < 32; k++) {                                   /* Berlekamp-Massey */
+        uint8_t d = S[k];
+        for (unsigned i = 1; i <= L; i++) d ^= gmul(L_[i], S[k - i]);
+        if (d == 0) { m++; continue; }
+        memcpy(T, L_, 33);
+        uint8_t coef = gdiv(d, b);
+        for (unsigned i = 0; i + m <= 32; i++) L_[i + m] ^= gmul(coef, B[i]);
+        if (2 * L <= k) { L = k + 1 - L; memcpy(B, T, 33); b = d; m = 1; } else m++;
+    }
+    if (L > 16) return;
+    uint8_t Om[32];                                                       /* Omega = S * Lambda mod x^32 */
+    for (unsigned i = 0; i < 32; i++) { uint8_t v = 0; for (unsigned j = 0; j <= i && j <= L; j++) v ^= gmul(L_[j], S[i - j]); Om[i] = v; }
+    unsigned pos[16], np = 0; uint8_t val[16];
+    for (unsigned j = 0; j < N; j++) {                                    /* Chien: symbol j has locator X = alpha^(N-1-j) */
+        unsigned e = (N - 1 - j) % 255, inv = (255 - e) % 255;            /* X^-1 = alpha^inv */
+        uint8_t v = 0;
+        for (unsigned i = 0; i <= L; i++) v ^= gmul(L_[i], rs_exp[(inv * i) % 255]);
+        if (v) continue;
+        if (np == 16) return;
+        uint8_t num = 0, den = 0;
+        for (unsigned i = 0; i < 32; i++) num ^= gmul(Om[i], rs_exp[(inv * i) % 255]);
+        for (unsigned i = 1; i <= L; i += 2) den ^= gmul(L_[i], rs_exp[(inv * (i - 1)) % 255]);   /* formal derivative */
+        if (den == 0) return;
+        pos[np] = j; val[np] = gdiv(num, den); np++;
+    }
+    if (np != L) return;                                                  /* locator does not split: uncorrectable */
+    for (unsigned i = 0; i < np; i++) r[pos[i]] ^= val[i];
+}
+static unsigned rs_enc_len(unsigned n) { unsigned nb, dl; rs_dims(n, &nb, &dl); return nb * (dl + 32); }
+static void rs_encode(unsigned n, const uint8_t *dec, uint8_t *enc)
+{
+    unsigned nb, dl; rs_dims(n, &nb, &dl); rs_init();
+    for (unsigned b = 0; b < nb; b++) {
+        uint8_t d[223]; memset(d, 0, sizeof d);
+        unsigned off = b * dl, len = off < n ? (n - off < dl ? n - off : dl) : 0;
+        memcpy(d, dec + off, len);
+        rs_encode_block(d, dl, enc + b * (dl + 32));
+    }
+}
+static void rs_decode(unsigned n, const uint8_t *enc, uint8_t *dec)
+{
+    unsigned nb, dl; rs_dims(n, &nb, &dl); rs_init();
+    for (unsigned b = 0; b < nb; b++) {
+        uint8_t r[255]; memcpy(r, enc + b * (dl + 32), dl + 32);
+        rs_decode_block(r, dl + 32);
+        unsigned off = b * dl, len = off < n ? (n - off < dl ? n - off : dl) : 0;
+        memcpy(dec + off, r, len);
+    }
+}
+
 /* ---------------------------------------------------------------- convolutional K=7 r=1/2 (+puncturing) */
 #define V27_A 0x6d
 #define V27_B 0x4f
@@ -384,7 +485,7 @@ int fxr_fec_supported(int fs)
 {
     unsigned k, n;
     return fs == FXR_FEC_NONE || fs == FXR_FEC_HAMMING84 || fs == FXR_FEC_SECDED7264 || fs == FXR_FEC_SECDED2216 ||
-           fs == FXR_FEC_SECDED3932 || blk_spec(fs, &k, &n) || punc_of(fs) != NULL;
+           fs == FXR_FEC_SECDED3932 || fs == FXR_FEC_RS_M8 || blk_spec(fs, &k, &n) || punc_of(fs) != NULL;
 }
 
 unsigned fxr_fec_enc_len(int fs, unsigned n)
@@ -394,6 +495,7 @@ unsigned fxr_fec_enc_len(int fs, unsigned n)
     unsigned bk, bn;
     if (blk_spec(fs, &bk, &bn)) return blk_enc_len(bk, bn, n);
     switch (fs) {
+    case FXR_FEC_RS_M8: return rs_enc_len(n);
     case FXR_FEC_SECDED2216: return 3 * (n / 2) + ((n % 2) ? (n % 2) + 1 : 0);
     case FXR_FEC_SECDED3932: return 5 * (n / 4) + ((n % 4) ? (n % 4) + 1 : 0);
     case FXR_FEC_HAMMING84: return 2 * n;
@@ -409,6 +511,7 @@ void fxr_fec_encode(int fs, unsigned n, const uint8_t *dec, uint8_t *enc)
     unsigned bk, bn;
     if (blk_spec(fs, &bk, &bn)) { blk_encode(fs, n, dec, enc); return; }
     switch (fs) {
+    case FXR_FEC_RS_M8: rs_encode(n, dec, enc); return;
     case FXR_FEC_SECDED2216: sdx_init(); sdx_encode(sd22_col, 2, n, dec, enc); return;
     case FXR_FEC_SECDED3932: sdx_init(); sdx_encode(sd39_col, 4, n, dec, enc); return;
     case FXR_FEC_HAMMING84:
@@ -435,6 +538,7 @@ void fxr_fec_decode(int fs, unsigned n, const uint8_t *enc, uint8_t *dec)
     unsigned bk, bn;
     if (blk_spec(fs, &bk, &bn)) { blk_decode(fs, n, enc, dec); return; }
     switch (fs) {
+    case FXR_FEC_RS_M8: rs_decode(n, enc, dec); return;
     case FXR_FEC_SECDED2216: sdx_init(); sdx_decode(sd22_col, 2, n, enc, dec); return;
     case FXR_FEC_SECDED3932: sdx_init(); sdx_decode(sd39_col, 4, n, enc, dec); return;
     case FXR_FEC_HAMMING84:

@@ -74,19 +74,19 @@ def test_product_tx_is_bit_identical_to_oracle_tx(fx, oracle):
 
 
 def test_product_tx_outer_codes_match_oracle(fx, oracle):
-    """every outer code the reference's flex_tx can select except RS (lib/flex_tx_impl.cc:148-181)"""
+    """every outer code the reference's flex_tx can select (lib/flex_tx_impl.cc:148-181)"""
     rng = np.random.default_rng(5)
-    for fec1 in (7, 4, 6, 8, 9, 10, 5):                          # Golay, H74, H128, SECDED22/39/72, H84
+    for fec1 in (7, 27, 4, 6, 8, 9, 10, 5):                      # Golay, RS, H74, H128, SECDED22/39/72, H84
         for fec0 in (1, 11, 15):
             n = int(rng.integers(1, 200))
             pl = rng.integers(0, 256, n, dtype=np.uint8)
             a = oracle.gen_frame(pl, mod=27, fec0=fec0, fec1=fec1, check=5)
             b = fx.FrameGen(27, fec0, fec1, 5).frame(pl)
             assert len(a) == len(b) and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (fec0, fec1, n)
-    with pytest.raises(ValueError):
-        fx.flex_tx.make(1, 1, 2)                                  # outer_code 2 = RS_M8: not built
-    for oc in (0, 1, 3, 4, 5, 6, 7):
+    for oc in range(8):                                           # every outer code of lib/flex_tx_impl.cc:148-181
         fx.flex_tx.make(1, 1, oc)
+    with pytest.raises(ValueError):
+        fx.FrameGen(2, 11, 12, 5)                                 # a liquid FEC id outside the reference's menu (CONV_V29)
 
 
 def test_flexframegen_dropin_contract(fx):

@@ -55,7 +55,7 @@ def test_all_modulations_and_codes_batched(fx, oracle):
 def test_outer_block_codes_and_checks(fx, oracle):
     xs = []
     for i, (f0, f1, chk) in enumerate([(1, 5, 6), (11, 10, 4), (20, 5, 3), (1, 10, 2), (15, 1, 1),
-                                       (11, 7, 5), (1, 4, 5), (15, 6, 5), (17, 8, 6), (1, 9, 5), (19, 7, 4)]):
+                                       (11, 7, 5), (1, 4, 5), (15, 6, 5), (17, 8, 6), (1, 9, 5), (19, 7, 4), (11, 27, 5), (1, 27, 6)]):
         x, _ = fx.synth_stream(40_000, stream_id=300 + i, mod=27, fec0=f0, fec1=f1, check=chk, payload_len=257, snr_db=30.0)
         xs.append(x)
     ctx = fx.RxContext(len(xs), want_framesyms=True)

@@ -92,7 +92,7 @@ def test_interleaver_is_a_bit_permutation_and_inverts(oracle):
             assert not np.array_equal(y, x)
 
 
-@pytest.mark.parametrize("fec", [1, 4, 5, 6, 7, 8, 9, 10, 11, 15, 16, 17, 18, 19, 20])
+@pytest.mark.parametrize("fec", [1, 4, 5, 6, 7, 8, 9, 10, 11, 15, 16, 17, 18, 19, 20, 27])
 def test_fec_roundtrip_and_error_correction(oracle, fec):
     L = oracle.lib()
     rng = np.random.default_rng(fec)
@@ -107,8 +107,8 @@ def test_fec_roundtrip_and_error_correction(oracle, fec):
             continue
         # isolated single-bit errors, far apart, must be corrected by every code in the menu
         bad = enc.copy()
-        step = 64 if fec >= 11 else {4: 7, 5: 8, 6: 12, 7: 24, 8: 24, 9: 40, 10: 72}[fec]
-        for b in range(3, 8 * el, step * 4 if fec >= 11 else step):
+        step = 64 if 11 <= fec <= 20 else {4: 7, 5: 8, 6: 12, 7: 24, 8: 24, 9: 40, 10: 72, 27: 200}[fec]
+        for b in range(3, 8 * el, step * 4 if 11 <= fec <= 20 else step):
             bad[b >> 3] ^= 0x80 >> (b & 7)
         L.fxr_fec_decode(fec, n, bad.ctypes.data, dec.ctypes.data)
         assert np.array_equal(dec[:n], msg)
