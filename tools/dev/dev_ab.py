@@ -8,7 +8,7 @@ for r in range(rounds):
         env = dict(os.environ)
         for kv in envs.split():
             k, val = kv.split("="); env[k] = val
-        out = subprocess.run([sys.executable, "bench.py", "--no-cpu-baseline"] + args.split(), capture_output=True, text=True, env=env)
+        out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "bench.py"), "--no-cpu-baseline"] + args.split(), capture_output=True, text=True, env=env)
         try:
             d = json.loads(out.stdout.strip().splitlines()[-1]); res[v].append(d["value"])
         except Exception as e:

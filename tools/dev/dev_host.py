@@ -1,5 +1,5 @@
 import importlib, sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 fx = importlib.import_module("gr-liquiddsp_amd")
 import torch
 xb, fb = fx.synth_stream(20_000_000, stream_id=0)
