@@ -54,7 +54,8 @@ class Timing(C.Structure):                  # fxrx_timing
                 ("paydec_ms", C.c_double), ("total_ms", C.c_double),
                 ("hops", C.c_uint64), ("walk_jobs", C.c_uint64), ("repairs", C.c_uint64),
                 ("frames", C.c_uint64), ("payload_symbols", C.c_uint64), ("samples", C.c_uint64), ("hops_cheap", C.c_uint64),
-                ("host_submit_ms", C.c_double), ("host_walkwait_ms", C.c_double)]
+                ("host_submit_ms", C.c_double), ("host_walkwait_ms", C.c_double),
+                ("seekverify_ms", C.c_double), ("verify_hops", C.c_uint64), ("verify_failures", C.c_uint64)]
 
 
 # every symbol include/fxrx.h declares (checked by tests/test_cabi.py)
@@ -114,6 +115,8 @@ def lib():
     L.fxrx_collect.restype = C.c_int; L.fxrx_collect.argtypes = [C.c_void_p]
     L.fxrx_set_depth.restype = C.c_int; L.fxrx_set_depth.argtypes = [C.c_void_p, C.c_uint]
     L.fxrx_debug_stamps.restype = C.c_int; L.fxrx_debug_stamps.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint32 * 8)]
+    L.fxrx_debug_walk_stamps.restype = C.c_int; L.fxrx_debug_walk_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
+    L.fxrx_debug_walk_maxjob.restype = C.c_int; L.fxrx_debug_walk_maxjob.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 8)]
     L.fxrx_device_framesyms.restype = C.c_void_p; L.fxrx_device_framesyms.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fxrx_last_timing.restype = C.c_int; L.fxrx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.fxrx_stream.restype = C.c_void_p; L.fxrx_stream.argtypes = [C.c_void_p]

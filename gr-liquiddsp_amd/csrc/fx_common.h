@@ -76,11 +76,16 @@ struct FxWalkJob {
     uint32_t frame_base;    // first slot of this job in the frame table
     uint32_t max_frames;    // slots available
     float    threshold;
+    uint32_t no_skip;       // 1: a locked flex_rx walker runs the full detector on every hop (exact by itself);
+                            // 0: it may skip hops its coarse scan finds empty -- the host then has every skipped hop
+                            //    checked by fx_seekverify_kernel before it trusts the chain
 };
 
-struct FxFrame {            // 128 bytes
+struct FxFrame {            // 152 bytes
     int64_t  start;         // index of aligned sample 0 (may be < floor: zeros there)
     int64_t  next;          // restart position after this frame (flex_rx) / next new-half (detect)
+    int64_t  seek_pos, seek_floor;   // the seek that led here started at this hop / with this floor ...
+    int64_t  det_pos;                // ... and detected at this hop: hops [seek_pos, det_pos) saw nothing
     int32_t  offset;        // CFO bin of the coarse search
     float    rxy, tau, gamma, dphi, phi;
     uint32_t pfb; int32_t mfc0;
@@ -101,7 +106,21 @@ struct FxWalkResult {
     uint32_t has_handoff;   // hand-off target valid
     int64_t  handoff_start; int32_t handoff_offset; uint32_t hops;
     float    handoff_rxy; uint32_t hops_cheap;
+    int64_t  tail_pos, tail_floor;   // the seek in progress at exit started here: hops [tail_pos, end) saw nothing,
+    int64_t  handoff_pos;            // end = handoff_pos (hop of the hand-off detection) or pos
     uint32_t stamp[4];      // diagnostic builds: shader clocks in coarse scan / exact seek / align / header
+};
+
+// ---- seek verification (fx_seekverify_kernel): a run of consecutive detector hops that must all come up empty ----
+struct FxVerifyJob {
+    const float2 *x; int64_t n;
+    int64_t  pos;           // first hop (new-half start); hop h sits at pos + 256 h
+    int64_t  floor;
+    uint32_t nhops; float threshold;
+};
+struct FxVerifyResult {
+    uint32_t det_hop;       // first hop of the run on which the detector fires, 0xFFFFFFFF if none
+    uint32_t bidx; int32_t boff; float peak;
 };
 
 // ---- payload stage records ----

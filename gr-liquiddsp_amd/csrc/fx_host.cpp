@@ -24,10 +24,11 @@
 
 extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, FxWalkResult *results,
                                      FxFrame *frames, const FxTables *T);
+extern "C" hipError_t fx_launch_seekverify(unsigned njobs, hipStream_t st, const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T);
 extern "C" __global__ void fx_paymf_kernel(const FxPayJob *, const uint32_t *, const uint32_t *, float2 *, const FxTables *);
-extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T);
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
                                        const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
                                        FxPayResult *res, const FxTables *T);
 
@@ -92,10 +93,10 @@ struct Out { fxrx_frame f; int pjob; };
 // block n, the packet decode of block n-1 and the walk of block n+1 can run concurrently on three streams.
 struct Slot {
     std::vector<FxPayJob> pjobs; std::vector<uint32_t> blk_job, blk_c0, pll_idx;
-    DevBuf<FxPayJob> d_pjobs; DevBuf<uint32_t> d_blk_job, d_blk_c0, d_pll_idx, d_dec_idx;
+    // payload-stage descriptors, one arena = one upload: [FxPayJob x NP | blk_job | blk_c0 | pll_idx | dec_idx]
+    DevBuf<uint8_t> d_meta; PinBuf<uint8_t> hp_meta;
     DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_out; DevBuf<unsigned long long> d_dw;
     DevBuf<FxPayResult> d_pres; PinBuf<FxPayResult> h_pres; PinBuf<uint8_t> h_out; PinBuf<float2> h_framesyms;
-    PinBuf<FxPayJob> hp_pjobs; PinBuf<uint32_t> hp_idx;          // pinned staging: H2D really is asynchronous
     std::vector<Out> out;
     uint64_t n_syms = 0;
     fxrx_timing timing{};
@@ -110,16 +111,21 @@ struct fxrx_ctx_s {
     // ones); streams that share a queue serialise.  So exactly three: W, and two payload streams used
     // alternately by consecutive blocks, each running its block's PLL -> decode -> result copies in order.
     hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
-    hipStream_t stream_p[4] = { nullptr, nullptr, nullptr, nullptr };   // payload PLL + packet decode, blocks round-robin
+    hipStream_t stream_p[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // payload PLL + packet decode, blocks round-robin
     unsigned n_pstreams = 2;
+    unsigned pll_waves = 1, dec_waves = 1;   // waves per workgroup of the PLL / decode grids (placement only)
+    unsigned pll_stagger = 32;               // blocks in flight start their PLL grids this many workgroup slots apart (0 = off)
     int n_cus = 256;
     hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;
+    hipEvent_t ev_last_mf = nullptr;     // end of the most recent payload MF (borrowed from its slot): guards the work buffers
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
     // walker (host-synchronised per submit, so one set suffices)
     std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
-    DevBuf<FxWalkJob> d_jobs; DevBuf<FxWalkResult> d_res; DevBuf<FxFrame> d_frames;
-    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames; PinBuf<FxWalkJob> hp_jobs;
+    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames; PinBuf<FxWalkJob> hp_jobs;   // device-visible (see launch_walk)
+    PinBuf<FxVerifyJob> hp_vjobs; PinBuf<FxVerifyResult> h_vres;                        // seek verification, likewise
+    hipEvent_t ev_v0 = nullptr, ev_v1 = nullptr;
+    bool skip_seek = true;               // FXRX_SKIP_SEEK=0: walkers run the full detector on every hop (no verification pass)
     // packet plans (shared, append-only)
     std::map<PlanKey, PlanDev> plans; std::vector<uint32_t> perm_host; DevBuf<uint32_t> d_perm; size_t perm_uploaded = 0;
     // pipeline
@@ -189,9 +195,11 @@ inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_
 
 int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
 {
+    // Job descriptors, per-job results and frame tables live in pinned host memory that the kernel addresses
+    // directly: each workgroup reads one descriptor and writes a handful of 128-byte records, so the PCIe hop costs
+    // less than the three staging copies it replaces on the walk -> stitch critical path.
     std::memcpy(c->hp_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob));
-    HIP_OK(hipMemcpyAsync(c->d_jobs.p + first, c->hp_jobs.p + first, count * sizeof(FxWalkJob), hipMemcpyHostToDevice, c->stream));
-    HIP_OK(fx_launch_walk(c->jobs[first].mode, (unsigned)count, c->stream, c->d_jobs.p + first, c->d_res.p + first, c->d_frames.p, c->d_tables));
+    HIP_OK(fx_launch_walk(c->jobs[first].mode, (unsigned)count, c->stream, c->hp_jobs.p + first, c->h_res.p + first, c->h_frames.p, c->d_tables));
     return 0;
 }
 
@@ -225,7 +233,10 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
-    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(4, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(8, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_PLL_WAVES")) c->pll_waves = (unsigned)std::min(4, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_PLL_STAGGER")) c->pll_stagger = (unsigned)std::min(256, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_DEC_WAVES")) c->dec_waves = (unsigned)std::min(8, std::max(1, std::atoi(e)));
     {
         // The walker fills every CU it may use (8 waves x 256 VGPRs = one register file).  Keeping it off a few CUs
         // (FXRX_WALK_CUS=<n>; bench.py uses 224 of 256) leaves room where the latency-critical PLL / decode
@@ -244,9 +255,25 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
         } else err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
         if (err != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
     }
-    for (unsigned i = 0; i < c->n_pstreams; i++)
-        if (hipStreamCreateWithFlags(&c->stream_p[i], hipStreamNonBlocking) != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
-    if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
+    {
+        // FXRX_PAYLOAD_SPLIT=1 (needs FXRX_WALK_CUS): the payload streams get exactly the CUs the walker leaves alone.
+        // A walker workgroup needs a whole, empty register file; decode waves of blocks in flight scattered over
+        // every CU make it wait for CUs to drain, so a hard partition can beat sharing.
+        const char *e = std::getenv("FXRX_PAYLOAD_SPLIT");
+        int ncu = 256; hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ncu = prop.multiProcessorCount;
+        const bool split = e && std::atoi(e) != 0 && c->n_cus < ncu;
+        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
+        for (int i = c->n_cus; i < ncu; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+        for (unsigned i = 0; i < c->n_pstreams; i++) {
+            const hipError_t err = split ? hipExtStreamCreateWithCUMask(&c->stream_p[i], (uint32_t)mask.size(), mask.data())
+                                         : hipStreamCreateWithFlags(&c->stream_p[i], hipStreamNonBlocking);
+            if (err != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
+        }
+    }
+    if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess ||
+        hipEventCreate(&c->ev_v0) != hipSuccess || hipEventCreate(&c->ev_v1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
+    if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (upload_tables(c.get()) != 0) return nullptr;
     c->st.resize(cfg->n_streams);
     if (make_slot(c.get()) != 0) return nullptr;
@@ -270,6 +297,8 @@ void fxrx_destroy(fxrx_ctx *c)
     }
     if (c->ev_w0) (void)hipEventDestroy(c->ev_w0);
     if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
+    if (c->ev_v0) (void)hipEventDestroy(c->ev_v0);
+    if (c->ev_v1) (void)hipEventDestroy(c->ev_v1);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (auto s : c->stream_p) if (s) (void)hipStreamDestroy(s);
@@ -325,6 +354,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         const uint64_t nn = n_samples[s];
         total_new += nn;
         if (S.carry_len == 0 && on_device) { xs[s] = (const float2 *)iq[s]; ns[s] = (int64_t)nn; continue; }
+        if (c->ev_last_mf) { HIP_OK(hipStreamWaitEvent(c->stream, c->ev_last_mf, 0)); c->ev_last_mf = nullptr; }   // that MF reads S.work
         if (S.work.reserve(S.carry_len + nn + 1)) return FXRX_ERR_HIP;
         if (S.carry_len) HIP_OK(hipMemcpyAsync(S.work.p, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
         if (nn) HIP_OK(hipMemcpyAsync(S.work.p + S.carry_len, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
@@ -366,6 +396,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start));
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
+            j.no_skip = (detect || !c->skip_seek) ? 1u : 0u;
             c->jobs.push_back(j); c->job_stream.push_back(s);
             p = j.stop; first = false;
             if (p >= ns[s]) break;
@@ -376,15 +407,12 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     // one spare job slot + frame region for repairs
     const uint32_t repair_base = frame_slots; const uint32_t repair_cap = 256;
     frame_slots += repair_cap;
-    if (c->d_jobs.reserve(NJ + 1) || c->d_res.reserve(NJ + 1) || c->h_res.reserve(NJ + 1) || c->hp_jobs.reserve(NJ + 1) ||
-        c->d_frames.reserve(frame_slots) || c->h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
+    if (c->h_res.reserve(NJ + 1) || c->hp_jobs.reserve(NJ + 1) || c->h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
     c->jobs.resize(NJ + 1);
 
     HIP_OK(hipEventRecord(c->ev_w0, c->stream));
     if (launch_walk(c, 0, NJ)) return FXRX_ERR_HIP;
     HIP_OK(hipEventRecord(c->ev_w1, c->stream));
-    HIP_OK(hipMemcpyAsync(c->h_res.p, c->d_res.p, NJ * sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
-    HIP_OK(hipMemcpyAsync(c->h_frames.p, c->d_frames.p, (size_t)repair_base * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
     {
         const auto tw = std::chrono::steady_clock::now();
         HIP_OK(hipStreamSynchronize(c->stream));
@@ -393,10 +421,15 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     sl.timing.walk_jobs = NJ;
 
     // ---- 3. stitch: per stream, splice speculative lists into the sequential chain ----
-    struct Chain { std::vector<FxFrame> frames; int64_t pos, floor_; bool fresh; };
+    // A chain also lists its seek spans: runs of hops [pos, end) on which the walkers reported no detection.  With
+    // hop skipping enabled these are what fx_seekverify_kernel re-checks with the full detector (step 3b).
+    struct Span { int64_t pos, floor_, end; };
+    struct Chain { std::vector<FxFrame> frames; std::vector<Span> spans; int64_t pos, floor_; bool fresh; };
     std::vector<Chain> chains(NS);
-    for (unsigned s = 0; s < NS; s++) {
+    auto stitch_stream = [&](unsigned s) -> int {
         Chain &ch = chains[s];
+        ch.frames.clear(); ch.spans.clear();
+        auto add_span = [&](int64_t p, int64_t fl, int64_t e) { if (e > p) ch.spans.push_back(Span{ p, fl, e }); };
         size_t cur = first_job[s]; uint32_t m = 0;
         FxWalkResult R = c->h_res.p[cur]; const FxFrame *F = c->h_frames.p + c->jobs[cur].frame_base;
         std::vector<FxFrame> repair_frames; float splice_rxy = -1.0f;
@@ -406,8 +439,6 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             j.frame_base = repair_base; j.max_frames = repair_cap;
             c->jobs[NJ] = j;
             if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(c->h_res.p + NJ, c->d_res.p + NJ, sizeof(FxWalkResult), hipMemcpyDeviceToHost, c->stream));
-            HIP_OK(hipMemcpyAsync(c->h_frames.p + repair_base, c->d_frames.p + repair_base, (size_t)repair_cap * sizeof(FxFrame), hipMemcpyDeviceToHost, c->stream));
             HIP_OK(hipStreamSynchronize(c->stream));
             sl.timing.repairs++;
             R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
@@ -424,7 +455,10 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
                 if (!(F[i].flags & FX_FLAG_EXACT)) continue;               // tentative pre-lock entries of a speculative walk
                 ch.frames.push_back(F[i]);
                 if (i == m && splice_rxy >= 0.0f) ch.frames.back().rxy = splice_rxy;   // coarse peak as the true chain saw it
+                else add_span(F[i].seek_pos, F[i].seek_floor, F[i].det_pos);            // (a spliced frame's seek is the hand-off's)
             }
+            // the seek in progress when this walker stopped (a spliced-in walker that contributed nothing is not on the chain)
+            if (!(spliced && nf <= m)) add_span(R.tail_pos, R.tail_floor, R.has_handoff ? R.handoff_pos : R.pos);
             splice_rxy = -1.0f;
             const bool last = (cur + 1 == first_job[s + 1]);
             if (R.exit_code == FX_EXIT_TABLE_FULL) {                       // continue the same segment where the table filled up
@@ -458,9 +492,56 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             if (run_repair(c->jobs[nxt], from)) return FXRX_ERR_HIP;
             cur = nxt;
         }
-    }
+        return 0;
+    };
+    for (unsigned s = 0; s < NS; s++) if (stitch_stream(s)) return FXRX_ERR_HIP;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, c->ev_w0, c->ev_w1); sl.timing.walk_ms = ms;
+
+    // ---- 3b. seek verification: the full detector over every hop the chains' walkers skipped ----
+    if (!detect && c->skip_seek) {
+        uint64_t tot_hops = 0;
+        for (unsigned s = 0; s < NS; s++) for (const Span &sp : chains[s].spans) tot_hops += (uint64_t)(sp.end - sp.pos) / FX_HOP;
+        // runs of at most `per` hops: about four workgroups per CU, so that the grid drains evenly
+        const uint64_t per = std::min<uint64_t>(16, std::max<uint64_t>(1, (tot_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
+        std::vector<FxVerifyJob> vj; std::vector<unsigned> vj_stream;
+        for (unsigned s = 0; s < NS; s++)
+            for (const Span &sp : chains[s].spans) {
+                const uint64_t nh = (uint64_t)(sp.end - sp.pos) / FX_HOP;
+                for (uint64_t h = 0; h < nh; h += per) {
+                    FxVerifyJob j{};
+                    j.x = xs[s]; j.n = ns[s]; j.pos = sp.pos + (int64_t)(h * FX_HOP); j.floor = sp.floor_;
+                    j.nhops = (uint32_t)std::min<uint64_t>(per, nh - h); j.threshold = c->cfg.threshold;
+                    vj.push_back(j); vj_stream.push_back(s);
+                }
+            }
+        sl.timing.verify_hops = tot_hops;
+        if (!vj.empty()) {
+            if (c->hp_vjobs.reserve(vj.size()) || c->h_vres.reserve(vj.size())) return FXRX_ERR_HIP;
+            std::memcpy(c->hp_vjobs.p, vj.data(), vj.size() * sizeof(FxVerifyJob));
+            HIP_OK(hipEventRecord(c->ev_v0, c->stream));
+            HIP_OK(fx_launch_seekverify((unsigned)vj.size(), c->stream, c->hp_vjobs.p, c->h_vres.p, c->d_tables));
+            HIP_OK(hipEventRecord(c->ev_v1, c->stream));
+            HIP_OK(hipStreamSynchronize(c->stream));
+            (void)hipEventElapsedTime(&ms, c->ev_v0, c->ev_v1); sl.timing.seekverify_ms = ms;
+            // A skipped hop on which the detector does fire (a false alarm, or a preamble too weak for the coarse
+            // scan): that stream's chain is void from there on.  Walk the stream again with skipping off -- exact
+            // by itself, as in the first version of this walker -- and stitch it again.
+            std::vector<char> bad(NS, 0); unsigned n_bad = 0;
+            for (size_t i = 0; i < vj.size(); i++)
+                if (c->h_vres.p[i].det_hop != 0xFFFFFFFFu && !bad[vj_stream[i]]) { bad[vj_stream[i]] = 1; n_bad++; }
+            if (n_bad) {
+                sl.timing.verify_failures = n_bad;
+                for (unsigned s = 0; s < NS; s++) {
+                    if (!bad[s]) continue;
+                    for (size_t j = first_job[s]; j < first_job[s + 1]; j++) c->jobs[j].no_skip = 1u;
+                    if (launch_walk(c, first_job[s], first_job[s + 1] - first_job[s])) return FXRX_ERR_HIP;
+                }
+                HIP_OK(hipStreamSynchronize(c->stream));
+                for (unsigned s = 0; s < NS; s++) if (bad[s] && stitch_stream(s)) return FXRX_ERR_HIP;
+            }
+        }
+    }
 
     // ---- 4. payload jobs ----
     sl.pjobs.clear(); sl.blk_job.clear(); sl.blk_c0.clear();
@@ -512,55 +593,57 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             c->perm_uploaded = c->perm_host.size();
         }
         const size_t NB = sl.blk_job.size();
-        if (sl.d_pjobs.reserve(NP) || sl.hp_pjobs.reserve(NP) || sl.d_blk_job.reserve(NB) || sl.d_blk_c0.reserve(NB) ||
-            sl.d_pll_idx.reserve(NP) || sl.d_dec_idx.reserve(NP) || sl.hp_idx.reserve(2 * NB + 2 * NP) ||
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const size_t o_blk = up16(NP * sizeof(FxPayJob)), o_c0 = o_blk + up16(NB * 4), o_pll = o_c0 + up16(NB * 4),
+                     o_dec = o_pll + up16(NP * 4), meta_bytes = o_dec + up16(NP * 4);
+        if (sl.d_meta.reserve(meta_bytes) || sl.hp_meta.reserve(meta_bytes) ||
             sl.d_symraw.reserve(sym_total + 8) || sl.d_framesyms.reserve(sym_total + 8) || sl.d_hard.reserve(sym_total + 64) ||
             sl.d_bufA.reserve(byte_total) || sl.d_bufB.reserve(byte_total) || sl.d_dw.reserve(dw_total) ||
             sl.d_out.reserve(out_total + 16) || sl.d_pres.reserve(NP) || sl.h_pres.reserve(NP) || sl.h_out.reserve(out_total + 16)) return FXRX_ERR_HIP;
+        const FxPayJob *d_pjobs = reinterpret_cast<const FxPayJob *>(sl.d_meta.p);
+        const uint32_t *d_blk_job = reinterpret_cast<const uint32_t *>(sl.d_meta.p + o_blk), *d_blk_c0 = reinterpret_cast<const uint32_t *>(sl.d_meta.p + o_c0),
+                       *d_pll_idx = reinterpret_cast<const uint32_t *>(sl.d_meta.p + o_pll), *d_dec_idx = reinterpret_cast<const uint32_t *>(sl.d_meta.p + o_dec);
         // group PLL jobs by modulation scheme (one grid per scheme: demodulator resolved at compile time)
         std::map<unsigned, std::vector<uint32_t>> by_ms;
         for (size_t i = 0; i < NP; i++) by_ms[sl.pjobs[i].ms].push_back((uint32_t)i);
         sl.pll_idx.clear();
         std::vector<std::tuple<unsigned, size_t, size_t>> groups;
         for (auto &kv : by_ms) { groups.emplace_back(kv.first, sl.pll_idx.size(), kv.second.size()); sl.pll_idx.insert(sl.pll_idx.end(), kv.second.begin(), kv.second.end()); }
-        std::memcpy(sl.hp_pjobs.p, sl.pjobs.data(), NP * sizeof(FxPayJob));
-        std::memcpy(sl.hp_idx.p, sl.blk_job.data(), NB * sizeof(uint32_t));
-        std::memcpy(sl.hp_idx.p + NB, sl.blk_c0.data(), NB * sizeof(uint32_t));
-        std::memcpy(sl.hp_idx.p + 2 * NB, sl.pll_idx.data(), NP * sizeof(uint32_t));
+        std::memcpy(sl.hp_meta.p, sl.pjobs.data(), NP * sizeof(FxPayJob));
+        std::memcpy(sl.hp_meta.p + o_blk, sl.blk_job.data(), NB * sizeof(uint32_t));
+        std::memcpy(sl.hp_meta.p + o_c0, sl.blk_c0.data(), NB * sizeof(uint32_t));
+        std::memcpy(sl.hp_meta.p + o_pll, sl.pll_idx.data(), NP * sizeof(uint32_t));
         // decode grids: frames without / with a Reed-Solomon stage (the latter use a heavier kernel instance)
         size_t n_plain = 0, n_rs = 0;
         {
-            uint32_t *di = sl.hp_idx.p + 2 * NB + NP;
+            uint32_t *di = reinterpret_cast<uint32_t *>(sl.hp_meta.p + o_dec);
             for (size_t i = 0; i < NP; i++) if (sl.pjobs[i].fec0 != FX_FEC_RS_M8 && sl.pjobs[i].fec1 != FX_FEC_RS_M8) di[n_plain++] = (uint32_t)i;
             for (size_t i = 0; i < NP; i++) if (sl.pjobs[i].fec0 == FX_FEC_RS_M8 || sl.pjobs[i].fec1 == FX_FEC_RS_M8) di[n_plain + n_rs++] = (uint32_t)i;
         }
-        // W: payload matched filter (the only payload stage that reads the IQ)
-        HIP_OK(hipMemcpyAsync(sl.d_pjobs.p, sl.hp_pjobs.p, NP * sizeof(FxPayJob), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(sl.d_blk_job.p, sl.hp_idx.p, NB * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(sl.d_blk_c0.p, sl.hp_idx.p + NB, NB * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(sl.d_pll_idx.p, sl.hp_idx.p + 2 * NB, NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipMemcpyAsync(sl.d_dec_idx.p, sl.hp_idx.p + 2 * NB + NP, NP * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_OK(hipEventRecord(sl.ev_mf0, c->stream));
-        hipLaunchKernelGGL(fx_paymf_kernel, dim3((unsigned)NB), dim3(256), 0, c->stream,
-                           sl.d_pjobs.p, sl.d_blk_job.p, sl.d_blk_c0.p, sl.d_symraw.p, c->d_tables);
+        // The whole payload stage runs on this block's payload stream, so that stream W is free for the next block's
+        // walk as soon as this one's is stitched.  The MF is the only payload kernel that reads the IQ; its input was
+        // staged on W before the walk, which the host has already waited for.
+        HIP_OK(hipMemcpyAsync(sl.d_meta.p, sl.hp_meta.p, meta_bytes, hipMemcpyHostToDevice, sl.stream_p));
+        HIP_OK(hipEventRecord(sl.ev_mf0, sl.stream_p));
+        hipLaunchKernelGGL(fx_paymf_kernel, dim3((unsigned)NB), dim3(256), 0, sl.stream_p,
+                           d_pjobs, d_blk_job, d_blk_c0, sl.d_symraw.p, c->d_tables);
         HIP_OK(hipGetLastError());
-        HIP_OK(hipEventRecord(sl.ev_mf1, c->stream));
+        HIP_OK(hipEventRecord(sl.ev_mf1, sl.stream_p));
+        c->ev_last_mf = sl.ev_mf1;
         // P: payload PLL
-        HIP_OK(hipStreamWaitEvent(sl.stream_p, sl.ev_mf1, 0));
-        HIP_OK(hipEventRecord(sl.ev_pll0, sl.stream_p));            // reached once the MF is done: kernel start, not queueing
+        HIP_OK(hipEventRecord(sl.ev_pll0, sl.stream_p));
         // stagger concurrent blocks' PLL grids over different CUs (see the kernel): slot k skips k * (grid rounded to 32)
-        const unsigned pll_wgs = (unsigned)((NP + 63) / 64);
-        const unsigned wg_skip = pll_wgs <= 128 ? c->head * ((pll_wgs + 31u) & ~31u) : 0u;
+        const unsigned pll_wgs = (unsigned)((NP + 64 * c->pll_waves - 1) / (64 * c->pll_waves));
+        const unsigned wg_skip = (c->pll_stagger && pll_wgs <= 128) ? c->head * ((pll_wgs + c->pll_stagger - 1u) / c->pll_stagger * c->pll_stagger) : 0u;
         for (auto &g : groups)
-            HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), wg_skip, sl.stream_p, sl.d_pjobs.p, sl.d_pll_idx.p + std::get<1>(g),
+            HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), wg_skip, c->pll_waves, sl.stream_p, d_pjobs, d_pll_idx + std::get<1>(g),
                                     sl.d_symraw.p, sl.d_framesyms.p, sl.d_hard.p, sl.d_pres.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev_pll1, sl.stream_p));
         // D: packet decode, results home
-        HIP_OK(hipStreamWaitEvent(sl.stream_d, sl.ev_pll1, 0));
         HIP_OK(hipEventRecord(sl.ev_dec0, sl.stream_d));
-        if (n_plain) HIP_OK(fx_launch_paydec(0, (unsigned)n_plain, sl.stream_d, sl.d_pjobs.p, sl.d_dec_idx.p, sl.d_hard.p, c->d_perm.p,
+        if (n_plain) HIP_OK(fx_launch_paydec(0, (unsigned)n_plain, c->dec_waves, sl.stream_d, d_pjobs, d_dec_idx, sl.d_hard.p, c->d_perm.p,
                                             sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables));
-        if (n_rs) HIP_OK(fx_launch_paydec(1, (unsigned)n_rs, sl.stream_d, sl.d_pjobs.p, sl.d_dec_idx.p + n_plain, sl.d_hard.p, c->d_perm.p,
+        if (n_rs) HIP_OK(fx_launch_paydec(1, (unsigned)n_rs, 1u, sl.stream_d, d_pjobs, d_dec_idx + n_plain, sl.d_hard.p, c->d_perm.p,
                                          sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_out.p, sl.d_pres.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev_dec1, sl.stream_d));
         HIP_OK(hipMemcpyAsync(sl.h_pres.p, sl.d_pres.p, NP * sizeof(FxPayResult), hipMemcpyDeviceToHost, sl.stream_d));
@@ -613,7 +696,7 @@ int fxrx_collect(fxrx_ctx *c)
         (void)hipEventElapsedTime(&ms, sl.ev_pll0, sl.ev_pll1); sl.timing.paypll_ms = ms;
         (void)hipEventElapsedTime(&ms, sl.ev_dec0, sl.ev_dec1); sl.timing.paydec_ms = ms;
     }
-    sl.timing.total_ms = sl.timing.walk_ms + sl.timing.paymf_ms + sl.timing.paypll_ms + sl.timing.paydec_ms;
+    sl.timing.total_ms = sl.timing.walk_ms + sl.timing.seekverify_ms + sl.timing.paymf_ms + sl.timing.paypll_ms + sl.timing.paydec_ms;
     sl.busy = false; c->last = &sl;
     c->tail = (c->tail + 1) % c->depth; c->inflight--;
     return (int)sl.out.size();

@@ -73,6 +73,61 @@ __device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_,
     return (p >= floor_ && p >= 0 && p < n) ? x[p] : make_float2(0.0f, 0.0f);
 }
 
+// One hop of the exact detector (qdetector SEEK): L.win holds the 512-sample window (overlap half + new half,
+// published by a barrier), x2_0 / x2_1 the energies of its halves.  Forward FFT, 49-bin CFO sweep, first maximum in
+// (bin, lag) order.  Shared by the walker and by fx_seekverify_kernel so that both take bit-identical decisions.
+// Called by the whole workgroup; result on every thread.
+__device__ __forceinline__ bool seek_sweep(WalkLds &L, float x2_0, float x2_1, float threshold, float s2sum, const float2 (&twA)[7],
+                                           const float2 (&twB)[7], int lane, int wave, uint32_t &bidx, int &boff, float &peak)
+{
+    const float g0 = sqrtf(x2_0 + x2_1) * sqrtf((float)FX_S_LEN / (float)FX_NFFT);
+    bidx = 0; boff = 0; peak = 0.0f;
+    if (g0 < 1e-10f) return false;
+    float2 a[8];
+    if (wave == 0) {                                          // forward FFT of the window
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = L.win[lane + 64 * q];
+        fft512_wave(a, L.scr[0], lane, twA, twB);
+        const int kb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+        for (int t = 0; t < 8; t++) L.X[kb + 64 * t] = a[t];
+    }
+    __syncthreads();
+    // CFO sweep: offsets -24..24 dealt round-robin to the waves
+    float bv = -1.0f; uint32_t bk = 0xFFFFFFFFu;
+    for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += WALK_WAVES) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = lane + 64 * q;
+            float2 y = cmulc(L.X[i], L.S[(i - off) & (FX_NFFT - 1)]);
+            a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
+        }
+        fft512_wave(a, L.scr[wave], lane, twA, twB);
+        const uint32_t kb = (uint32_t)(off + FX_RANGE) * FX_NFFT + (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+        for (int t = 0; t < 8; t++) {
+            float m = fmaf(a[t].y, a[t].y, a[t].x * a[t].x);  // |R|^2, R = (a.y, a.x)
+            uint32_t k = kb + 64 * t;
+            bool take = (m > bv) || (m == bv && k < bk);
+            bv = take ? m : bv; bk = take ? k : bk;
+        }
+    }
+    wave_argmax(bv, bk);
+    if (lane == 0) { L.redv[wave] = bv; L.redk[wave] = bk; }
+    __syncthreads();
+    bv = L.redv[0]; bk = L.redk[0];
+#pragma unroll
+    for (int w = 1; w < WALK_WAVES; w++) {
+        float ov = L.redv[w]; uint32_t ok = L.redk[w];
+        bool take = (ov > bv) || (ov == bv && ok < bk);
+        bv = take ? ov : bv; bk = take ? ok : bk;
+    }
+    const float g = 1.0f / ((float)FX_NFFT * g0 * sqrtf(s2sum));
+    peak = sqrtf(bv) * g;
+    bidx = bk & (FX_NFFT - 1); boff = (int)(bk >> 9) - FX_RANGE;
+    return (peak > threshold) && (bidx < FX_NFFT - FX_S_LEN);
+}
+
 // header: 54 received bytes (L.b0) -> 20 header bytes (L.b1[0..19]) + CRC verdict (L.u[1]).
 // Called by the whole workgroup; every stage is spread over threads (a one-thread version of this cost more
 // than the rest of the header span together).
@@ -150,8 +205,13 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     int64_t pos = job.start, floor_ = job.floor;
     bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
     uint32_t nfr = 0, hops = 0, hops_cheap = 0, exact_left = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
-    int64_t ho_start = 0; int32_t ho_off = 0; float ho_rxy = 0.0f;
+    int64_t ho_start = 0, ho_pos = 0; int32_t ho_off = 0; float ho_rxy = 0.0f;
     float x2_0 = 0.0f;
+    // A locked flex_rx walker may skip hops its coarse scan finds empty (job.no_skip == 0): it stays on the true hop
+    // grid and runs the exact detector only around coarse-scan candidates; the host has every hop between
+    // span_pos and the next detection re-checked by fx_seekverify_kernel.
+    const bool may_skip = MODE == FX_MODE_FLEXRX && job.no_skip == 0;
+    int64_t span_pos = pos, span_floor = floor_;
 #ifdef FX_STAMPS
     unsigned long long wt_ = __builtin_readcyclecounter(); uint32_t wst_[4] = { 0, 0, 0, 0 };
 #define WSTAMP(i) do { unsigned long long t2_ = __builtin_readcyclecounter(); wst_[i] += (uint32_t)(t2_ - wt_); wt_ = t2_; } while (0)
@@ -176,7 +236,8 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         // ------------------------------------------------------------ pre-lock coarse scan, four hops at a time
         // (same differential correlator as the single-hop form below, one window per wave, no block barriers
         // inside; used while at least four hops remain before the segment end / end of data)
-        if (!locked && MODE == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n && pos + (WALK_WAVES - 1) * FX_HOP < job.stop) {
+        if ((!locked || may_skip) && MODE == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n &&
+            (in_handoff || pos + (WALK_WAVES - 1) * FX_HOP < job.stop)) {
             __syncthreads();
             for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(x, pos - FX_HOP + i, floor_, n);
             __syncthreads();
@@ -217,12 +278,26 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             int hw = -1;
 #pragma unroll
             for (int w = WALK_WAVES - 1; w >= 0; w--) if (L.cand[w] != 0xFFFFFFFFu) hw = w;
-            if (hw >= 0) {
+            if (hw >= 0 && locked) {
+                // candidate in the window of grid hop hw: resume the exact detector there (one hop earlier when the
+                // candidate sits at the very start of the window -- the two correlators may disagree by a sample)
+                exact_left = 3;
+                if (L.cand[hw] < 8u && hw > 0) { hw--; exact_left = 4; }
+                hops_cheap -= WALK_WAVES - hw;
+                if (hw > 0) {
+                    const float2 w = lo ? L.cw[FX_HOP * hw + tid] : make_float2(0.0f, 0.0f);
+                    if (lo) L.win[tid] = w;
+                    x2_0 = block_sum256(cm2(w), L, lane, wave);
+                    pos += (int64_t)FX_HOP * hw; fresh = false;
+                }
+            } else if (hw >= 0) {
                 const int64_t p = pos - FX_HOP + (int64_t)FX_HOP * hw + (int64_t)L.cand[hw];
                 pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
                 if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
             } else {
-                if (lo) L.win[tid] = L.cw[WALK_WAVES * FX_HOP + tid];    // last hop becomes the overlap half
+                const float2 w = lo ? L.cw[WALK_WAVES * FX_HOP + tid] : make_float2(0.0f, 0.0f);
+                if (lo) L.win[tid] = w;                                  // last hop becomes the overlap half
+                if (locked) x2_0 = block_sum256(cm2(w), L, lane, wave);  // (a walker not yet locked re-arms fresh on a hit)
                 pos += WALK_WAVES * FX_HOP; fresh = false;
             }
             __syncthreads();
@@ -238,7 +313,8 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         // for its first preamble any way it likes.  A CFO-blind differential correlator needs 2 FFTs per hop
         // instead of the 50 of the real detector: d[i] = w[i+1] conj(w[i]) against the zero-mean td[k] = s[k+1] conj(s[k]).
         // A hit at lag l re-arms the exact detector (fresh) one hop before the candidate.
-        if (!locked && MODE == FX_MODE_FLEXRX && exact_left == 0) {
+        bool coarse_hit = false;
+        if ((!locked || may_skip) && MODE == FX_MODE_FLEXRX && exact_left == 0) {
             __syncthreads();
             hops_cheap++;
             float2 d0 = lo ? cmulc(L.win[tid + 1], L.win[tid]) : make_float2(0.0f, 0.0f);
@@ -274,70 +350,31 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             __syncthreads();
             const float cpk = L.f[4]; const uint32_t cl = L.u[8];
             if (cpk > 0.06f * ed * T->td2sum * (float)FX_NFFT * (float)FX_NFFT && ed > 0.0f) {
-                // candidate preamble at p: restart the exact detector, fresh, one hop earlier
-                const int64_t p = pos - FX_HOP + (int64_t)cl;
-                pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
-                if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
+                if (locked) { coarse_hit = true; exact_left = 3; hops_cheap--; }   // run the exact detector on this very hop
+                else {
+                    // candidate preamble at p: restart the exact detector, fresh, one hop earlier
+                    const int64_t p = pos - FX_HOP + (int64_t)cl;
+                    pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
+                    if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
+                    __syncthreads();
+                    continue;
+                }
+            }
+            if (!coarse_hit) {
+                if (lo) L.win[tid] = nw;
+                if (locked) x2_0 = block_sum256(cm2(nw), L, lane, wave);
+                pos += FX_HOP; fresh = false;
                 __syncthreads();
                 continue;
             }
-            if (lo) L.win[tid] = nw;
-            pos += FX_HOP; fresh = false;
-            __syncthreads();
-            continue;
         }
         if (exact_left) exact_left--;
 
         // ------------------------------------------------------------ SEEK: one 256-sample hop
         const float x2_1 = block_sum256(cm2(nw), L, lane, wave);     // barriers inside publish win[]
         hops++;
-        const float g0 = sqrtf(x2_0 + x2_1) * sqrtf((float)FX_S_LEN / (float)FX_NFFT);
-        bool det = false; uint32_t bidx = 0; int boff = 0; float peak = 0.0f;
-        if (!(g0 < 1e-10f)) {
-            float2 a[8];
-            if (wave == 0) {                                          // forward FFT of the window
-#pragma unroll
-                for (int q = 0; q < 8; q++) a[q] = L.win[lane + 64 * q];
-                fft512_wave(a, L.scr[0], lane, twA, twB);
-                const int kb = (lane >> 3) + 8 * (lane & 7);
-#pragma unroll
-                for (int t = 0; t < 8; t++) L.X[kb + 64 * t] = a[t];
-            }
-            __syncthreads();
-            // CFO sweep: offsets -24..24 dealt round-robin to the 4 waves
-            float bv = -1.0f; uint32_t bk = 0xFFFFFFFFu;
-            for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += WALK_WAVES) {
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const int i = lane + 64 * q;
-                    float2 y = cmulc(L.X[i], L.S[(i - off) & (FX_NFFT - 1)]);
-                    a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
-                }
-                fft512_wave(a, L.scr[wave], lane, twA, twB);
-                const uint32_t kb = (uint32_t)(off + FX_RANGE) * FX_NFFT + (lane >> 3) + 8 * (lane & 7);
-#pragma unroll
-                for (int t = 0; t < 8; t++) {
-                    float m = fmaf(a[t].y, a[t].y, a[t].x * a[t].x);  // |R|^2, R = (a.y, a.x)
-                    uint32_t k = kb + 64 * t;
-                    bool take = (m > bv) || (m == bv && k < bk);
-                    bv = take ? m : bv; bk = take ? k : bk;
-                }
-            }
-            wave_argmax(bv, bk);
-            if (lane == 0) { L.redv[wave] = bv; L.redk[wave] = bk; }
-            __syncthreads();
-            bv = L.redv[0]; bk = L.redk[0];
-#pragma unroll
-            for (int w = 1; w < WALK_WAVES; w++) {
-                float ov = L.redv[w]; uint32_t ok = L.redk[w];
-                bool take = (ov > bv) || (ov == bv && ok < bk);
-                bv = take ? ov : bv; bk = take ? ok : bk;
-            }
-            const float g = 1.0f / ((float)FX_NFFT * g0 * sqrtf(s2sum));
-            peak = sqrtf(bv) * g;
-            bidx = bk & (FX_NFFT - 1); boff = (int)(bk >> 9) - FX_RANGE;
-            det = (peak > job.threshold) && (bidx < FX_NFFT - FX_S_LEN);
-        }
+        bool det; uint32_t bidx; int boff; float peak;
+        det = seek_sweep(L, x2_0, x2_1, job.threshold, s2sum, twA, twB, lane, wave, bidx, boff, peak);
         WSTAMP(1);
         if (!det) {                                                    // slide the window by one hop
             __syncthreads();
@@ -348,7 +385,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         }
 
         const int64_t a0 = pos - FX_HOP + (int64_t)bidx;
-        if (in_handoff) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; exit_code = FX_EXIT_STOP; break; }
+        if (in_handoff) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = pos; exit_code = FX_EXIT_STOP; break; }
         if (nfr >= job.max_frames) { exit_code = FX_EXIT_TABLE_FULL; break; }
         if (a0 + FX_NFFT > n) { exit_code = FX_EXIT_NEED_DATA; break; }
 
@@ -434,6 +471,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         WSTAMP(2);
         FxFrame fr;
         fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
+        fr.seek_pos = span_pos; fr.seek_floor = span_floor; fr.det_pos = pos;
         fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
         fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f; fr.flags = 0;
         fr.pay_len = fr.ms = fr.check = fr.fec0 = fr.fec1 = fr.pay_sym_len = 0;
@@ -584,6 +622,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         if (incomplete) { exit_code = FX_EXIT_PAYLOAD; break; }
         // synchroniser reset: fresh detector right after the frame's last symbol
         pos = fr.next; floor_ = fr.next; fresh = true; x2_0 = 0.0f;
+        span_pos = pos; span_floor = floor_;
         __syncthreads();
         if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
         __syncthreads();
@@ -594,6 +633,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
         r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
         r.handoff_rxy = ho_rxy; r.hops_cheap = hops_cheap;
+        r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos;
 #ifdef FX_STAMPS
         for (int i = 0; i < 4; i++) r.stamp[i] = wst_[i];
 #else
@@ -608,6 +648,50 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t 
 {
     if (mode == FX_MODE_DETECT) hipLaunchKernelGGL(fx_walk_kernel<FX_MODE_DETECT>, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, frames, T);
     else hipLaunchKernelGGL(fx_walk_kernel<FX_MODE_FLEXRX>, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, frames, T);
+    return hipGetLastError();
+}
+
+// ===================================================================== seek verification
+// A run of consecutive hops of the exact detector, all expected to come up empty (the hops a locked walker skipped
+// on the strength of its coarse scan).  Hops are independent given (pos, floor), so the runs are cut to spread over
+// the whole chip; the workgroup slides its window exactly like the walker does.
+__global__ __launch_bounds__(WALK_THREADS, FX_DETECT_OCC)
+void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
+{
+    __shared__ WalkLds L;
+    const FxVerifyJob job = jobs[blockIdx.x];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float2 twA[7], twB[7];
+#pragma unroll
+    for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
+    for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
+    const float s2sum = T->s2sum;
+    const bool lo = tid < HALF;
+    int64_t pos = job.pos;
+    float2 w = lo ? xv(job.x, pos - FX_HOP + tid, job.floor, job.n) : make_float2(0.0f, 0.0f);
+    if (lo) L.win[tid] = w;
+    float x2_0 = block_sum256(cm2(w), L, lane, wave);
+    FxVerifyResult r; r.det_hop = 0xFFFFFFFFu; r.bidx = 0; r.boff = 0; r.peak = 0.0f;
+    for (uint32_t h = 0; h < job.nhops; h++) {
+        const float2 nw = lo ? xv(job.x, pos + tid, job.floor, job.n) : make_float2(0.0f, 0.0f);
+        if (lo) L.win[FX_HOP + tid] = nw;
+        const float x2_1 = block_sum256(cm2(nw), L, lane, wave);
+        uint32_t bidx; int boff; float peak;
+        if (seek_sweep(L, x2_0, x2_1, job.threshold, s2sum, twA, twB, lane, wave, bidx, boff, peak)) {
+            r.det_hop = h; r.bidx = bidx; r.boff = boff; r.peak = peak;
+            break;
+        }
+        __syncthreads();
+        if (lo) L.win[tid] = nw;
+        x2_0 = x2_1; pos += FX_HOP;
+        __syncthreads();
+    }
+    if (tid == 0) results[blockIdx.x] = r;
+}
+
+extern "C" hipError_t fx_launch_seekverify(unsigned njobs, hipStream_t st, const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
+{
+    hipLaunchKernelGGL(fx_seekverify_kernel, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, T);
     return hipGetLastError();
 }
 
@@ -654,6 +738,7 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
 // (one block ahead, 64 contiguous bytes per lane), results leave as 16-byte stores, the sin/cos table sits
 // in LDS and the four PSK2/PSK4 constellation points in registers.
 #define PLL_THREADS 64
+#define PLL_MAX_WAVES 4       // waves per workgroup is a launch-time placement knob (one wave per SIMD of a CU at 4)
 #define PLL_BLK     8
 
 __device__ __forceinline__ void pll_load8(const float4 *p, float4 b[4]) { b[0] = p[0]; b[1] = p[1]; b[2] = p[2]; b[3] = p[3]; }
@@ -690,7 +775,7 @@ __device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const fl
 }
 
 template <int MS>
-__global__ __launch_bounds__(PLL_THREADS)
+__global__ __launch_bounds__(PLL_THREADS * PLL_MAX_WAVES)
 void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, uint32_t wg_skip, const float2 *sym_raw,
                       float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
 {
@@ -702,9 +787,9 @@ void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
     // blocks in flight, let it win the issue arbitration
     __builtin_amdgcn_s_setprio(3);
     __shared__ float2 sc[1024];
-    for (int i = threadIdx.x; i < 1024; i += PLL_THREADS) sc[i] = T->sc[i];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) sc[i] = T->sc[i];
     __syncthreads();
-    const uint32_t li = (blockIdx.x - wg_skip) * PLL_THREADS + threadIdx.x;
+    const uint32_t li = (blockIdx.x - wg_skip) * blockDim.x + threadIdx.x;
     if (li >= njobs) return;
     const uint32_t f = job_idx[li];
     const FxPayJob job = jobs[f];
@@ -748,10 +833,11 @@ void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
 }
 
 // host-side launcher (lives here so that the template instantiations stay in this translation unit)
-extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
 {
-    const dim3 grid((njobs + PLL_THREADS - 1) / PLL_THREADS + wg_skip), block(PLL_THREADS);
+    const unsigned w = waves_per_wg < 1u ? 1u : (waves_per_wg > PLL_MAX_WAVES ? PLL_MAX_WAVES : waves_per_wg);
+    const dim3 block(PLL_THREADS * w), grid((njobs + block.x - 1) / block.x + wg_skip);
 #define FX_PLL_CASE(M) case M: hipLaunchKernelGGL(fx_paypll_kernel<M>, grid, block, 0, st, jobs, job_idx, njobs, wg_skip, sym_raw, framesyms, hard, res, T); break;
     switch (ms) {
         FX_PLL_CASE(FX_MODEM_PSK2) FX_PLL_CASE(FX_MODEM_PSK4) FX_PLL_CASE(FX_MODEM_PSK8) FX_PLL_CASE(FX_MODEM_PSK16)
@@ -1160,20 +1246,27 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 
 // WITH_RS: the Reed-Solomon decoder keeps ~150 bytes of per-lane state; frames that use it go through their own
 // instance so that every other frame keeps the lean (39-VGPR, 8 waves/SIMD) one.  job_idx lists this grid's frames.
+//
+// Waves never talk to each other (no LDS, no barrier), so the workgroup size is only a placement knob: wide
+// workgroups keep a block's decode waves together on few CUs instead of sprinkling one wave over every CU, which
+// matters to the walker of the next block (its workgroups need a whole, empty register file each).
+#define DEC_MAX_WAVES 8
 template <bool WITH_RS>
-__global__ __launch_bounds__(DEC_THREADS)
-void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB,
-                      unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
+__global__ __launch_bounds__(WITH_RS ? DEC_THREADS : DEC_THREADS * DEC_MAX_WAVES)
+void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA,
+                      uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
 {
     __builtin_amdgcn_s_setprio(2);
-    const uint32_t jf = job_idx[blockIdx.x];
+    const uint32_t ji = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (ji >= njobs) return;
+    const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
     // one wave per frame: pin the loop bounds into SGPRs so that every loop below is scalar-controlled
     job.l0 = __builtin_amdgcn_readfirstlane(job.l0); job.l1 = __builtin_amdgcn_readfirstlane(job.l1);
     job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
     job.fec0 = __builtin_amdgcn_readfirstlane(job.fec0); job.fec1 = __builtin_amdgcn_readfirstlane(job.fec1);
     job.bps = __builtin_amdgcn_readfirstlane(job.bps); job.check = __builtin_amdgcn_readfirstlane(job.check);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
     const uint8_t *hs = hard + job.sym_off;
     const unsigned bps = job.bps;
@@ -1240,11 +1333,13 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const uint8
     FX_STAMP(5);
 }
 
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
                                        const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
                                        FxPayResult *res, const FxTables *T)
 {
-    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, job_idx, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
-    else hipLaunchKernelGGL(fx_paydec_kernel<false>, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, job_idx, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
+    const unsigned w = with_rs ? 1u : (waves_per_wg < 1u ? 1u : (waves_per_wg > DEC_MAX_WAVES ? DEC_MAX_WAVES : waves_per_wg));
+    const dim3 grid((njobs + w - 1) / w), block(DEC_THREADS * w);
+    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, grid, block, 0, st, jobs, job_idx, njobs, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
+    else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, njobs, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
     return hipGetLastError();
 }

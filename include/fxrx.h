@@ -178,6 +178,8 @@ typedef struct {
     double   walk_ms, paymf_ms, paypll_ms, paydec_ms, total_ms;   /* HIP-event times of the last call */
     uint64_t hops, walk_jobs, repairs, frames, payload_symbols, samples, hops_cheap;
     double   host_submit_ms, host_walkwait_ms;   /* wall time spent inside fxrx_submit / of that, waiting for the walker */
+    double   seekverify_ms;                      /* fx_seekverify_kernel (full detector over the hops the walkers skipped) */
+    uint64_t verify_hops, verify_failures;       /* hops re-checked / streams walked again because a skipped hop fired */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
 /* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */

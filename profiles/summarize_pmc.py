@@ -4,7 +4,7 @@ Units / corrections (MI355X_MICROARCH.md, section HBM): FETCH_SIZE and WRITE_SIZ
 reported by rocprofv3 (value * 1024 = bytes); on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced
 streams, i.e. reads half the bytes -> corrected fetch = 2 x raw.  WRITE_SIZE is taken as is.  Access patterns other
 than 16-B-per-lane streams are uncalibrated; both raw and corrected figures are kept."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 root = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out"
@@ -16,7 +16,8 @@ def load(sub, counter):
         for r in csv.DictReader(open(f)):
             if r.get("Counter_Name") == counter:
                 name = r["Kernel_Name"]
-                name = "fx_paypll_kernel" if "paypll" in name else name
+                m = re.search(r"fx_\w+_kernel", name)     # "void fx_walk_kernel<0>(...)" -> "fx_walk_kernel"
+                name = m.group(0) if m else name
                 acc[name].append(float(r["Counter_Value"]))
     return acc
 
