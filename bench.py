@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 # Runtime knobs, set before anything initialises HIP.  The pipeline keeps several blocks in flight on separate HIP
 # streams; HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them torch's), and
-# streams that share a queue serialise.  Eight queues let the walker stream and three payload streams run concurrently.
+# streams that share a queue serialise.  Eight queues let the walker stream and six payload streams run concurrently.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "3")
+os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "6")
 os.environ.setdefault("FXRX_WALK_CUS", "224")      # walker kept off 32 CUs: PLL / decode waves of blocks in flight start at once
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one block in flight (latency mode)")
-    ap.add_argument("--depth", type=int, default=6, help="blocks in flight in the timed region")
+    ap.add_argument("--depth", type=int, default=8, help="blocks in flight in the timed region")
     ap.add_argument("--segment", type=int, default=0, help="speculation segment length in samples (0 = library default)")
     a = ap.parse_args()
 
@@ -136,7 +136,7 @@ def main():
 
     # per-kernel device times (HIP events on the library's own streams), taken un-pipelined so that they are
     # pure kernel durations: these feed `roofline` and `kernels_ms`
-    kt = dict(walk_ms=0.0, paymf_ms=0.0, paypll_ms=0.0, paydec_ms=0.0, total_ms=0.0)
+    kt = dict(walk_ms=0.0, seekverify_ms=0.0, paymf_ms=0.0, paypll_ms=0.0, paydec_ms=0.0, total_ms=0.0)
     for i in range(max(a.warmup, 1) + 3):
         ctx.reset()
         nres = ctx.process_raw(ptrs, counts, True)
@@ -150,7 +150,7 @@ def main():
     depth = 1 if a.no_pipeline else a.depth
     ctx.set_depth(depth)
 
-    kt_live = dict(walk_ms=0.0, paymf_ms=0.0, paypll_ms=0.0, paydec_ms=0.0)
+    kt_live = dict(walk_ms=0.0, seekverify_ms=0.0, paymf_ms=0.0, paypll_ms=0.0, paydec_ms=0.0, host_submit_ms=0.0, host_walkwait_ms=0.0)
 
     def collect():
         n = ctx.collect_raw()
@@ -184,7 +184,8 @@ def main():
     if rank == 0:
         ms_step = dt / a.steps * 1e3
         value = world * a.samples / (dt / a.steps) / 1e6
-        names = dict(walk_ms="fx_walk_kernel", paymf_ms="fx_paymf_kernel", paypll_ms="fx_paypll_kernel", paydec_ms="fx_paydec_kernel")
+        names = dict(walk_ms="fx_walk_kernel", seekverify_ms="fx_seekverify_kernel", paymf_ms="fx_paymf_kernel",
+                     paypll_ms="fx_paypll_kernel", paydec_ms="fx_paydec_kernel")
         live = {k: kt_live[k] / a.steps for k in kt_live}    # average launch duration inside the timed region
         dom = max(names, key=lambda k: live[k])
         alg_bytes = BYTES_PER_SAMPLE * a.samples
@@ -204,6 +205,7 @@ def main():
             "kernels_ms": {names[k]: round(live[k], 4) for k in names},
             "kernels_ms_one_block_in_flight": {names[k]: round(kt[k], 4) for k in names},
             "device_ms_per_step": round(kt["total_ms"], 4),
+            "host_ms_per_step": {"in_submit": round(live["host_submit_ms"], 4), "of_which_waiting_for_walker": round(live["host_walkwait_ms"], 4)},
             "whole_path_hbm_gbs": round(alg_bytes / (dt / a.steps) / 1e9, 2),
         }
         if world == 1 and not a.no_cpu_baseline:

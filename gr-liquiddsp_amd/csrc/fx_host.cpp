@@ -522,7 +522,11 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             HIP_OK(hipEventRecord(c->ev_v0, c->stream));
             HIP_OK(fx_launch_seekverify((unsigned)vj.size(), c->stream, c->hp_vjobs.p, c->h_vres.p, c->d_tables));
             HIP_OK(hipEventRecord(c->ev_v1, c->stream));
-            HIP_OK(hipStreamSynchronize(c->stream));
+            {
+                const auto tw = std::chrono::steady_clock::now();
+                HIP_OK(hipStreamSynchronize(c->stream));
+                sl.timing.host_walkwait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+            }
             (void)hipEventElapsedTime(&ms, c->ev_v0, c->ev_v1); sl.timing.seekverify_ms = ms;
             // A skipped hop on which the detector does fire (a false alarm, or a preamble too weak for the coarse
             // scan): that stream's chain is void from there on.  Walk the stream again with skipping off -- exact

@@ -67,6 +67,12 @@ __device__ __forceinline__ float2 block_csum256(float2 v, WalkLds &L, int lane, 
     return cadd(a, b);
 }
 
+__device__ __forceinline__ int64_t uniform64(int64_t v)
+{
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)v >> 32));
+    return (int64_t)(((uint64_t)hi << 32) | lo);
+}
+
 // samples below `floor` (before the last synchroniser reset) and outside the stream read as zero
 __device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_, int64_t n)
 {
@@ -227,6 +233,11 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     __syncthreads();
 
     for (;;) {
+        // the walk state is uniform across the workgroup: say so, so that it lives in scalar registers
+        pos = uniform64(pos); floor_ = uniform64(floor_); span_pos = uniform64(span_pos); span_floor = uniform64(span_floor);
+        x2_0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x2_0)));
+        nfr = __builtin_amdgcn_readfirstlane(nfr); hops = __builtin_amdgcn_readfirstlane(hops); hops_cheap = __builtin_amdgcn_readfirstlane(hops_cheap);
+        exact_left = __builtin_amdgcn_readfirstlane(exact_left);
         if (pos >= job.stop && !in_handoff) {
             // a speculative walker that never locked has nothing to hand off (its state is not the chain's)
             if (job.handoff && locked) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }

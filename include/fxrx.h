@@ -177,7 +177,7 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n_symbols);
 typedef struct {
     double   walk_ms, paymf_ms, paypll_ms, paydec_ms, total_ms;   /* HIP-event times of the last call */
     uint64_t hops, walk_jobs, repairs, frames, payload_symbols, samples, hops_cheap;
-    double   host_submit_ms, host_walkwait_ms;   /* wall time spent inside fxrx_submit / of that, waiting for the walker */
+    double   host_submit_ms, host_walkwait_ms;   /* wall time spent inside fxrx_submit / of that, waiting for the walker + seek verification */
     double   seekverify_ms;                      /* fx_seekverify_kernel (full detector over the hops the walkers skipped) */
     uint64_t verify_hops, verify_failures;       /* hops re-checked / streams walked again because a skipped hop fired */
 } fxrx_timing;
