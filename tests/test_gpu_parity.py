@@ -326,3 +326,28 @@ def test_pipelined_multi_stream_detector_mode(fx, oracle):
         mine = [g for g in got if g["stream"] == s]
         assert [d["pos"] for d in od if d["pos"] + 512 <= 200_000] == [g["start"] for g in mine][:len([d for d in od if d["pos"] + 512 <= 200_000])]
         assert len(mine) >= 10
+
+
+@pytest.mark.gpu
+def test_skipped_hops_are_verified_and_weak_preambles_fall_back(fx, oracle):
+    """Locked walkers skip hops their coarse scan finds empty; fx_seekverify_kernel re-checks each with the full
+    detector.  Weak preambles (full correlator fires, differential coarse scan does not) must come out exactly as the
+    sequential oracle has them -- through the per-stream fallback walk -- and the fallback must actually be exercised."""
+    rng = np.random.default_rng(2025)
+    g = fx.FrameGen()
+    failures = hops = 0
+    for trial in range(6):
+        parts = [np.zeros(300, np.complex64), g.frame(rng.integers(0, 256, 64, dtype=np.uint8))]
+        for k in range(10):
+            amp = rng.uniform(0.18, 0.5)                                     # around the detector's threshold in this noise
+            parts += [np.zeros(int(rng.integers(300, 3000)), np.complex64), amp * g.frame(rng.integers(0, 256, 64, dtype=np.uint8))]
+        parts += [np.zeros(700, np.complex64), g.frame(rng.integers(0, 256, 64, dtype=np.uint8)), np.zeros(2000, np.complex64)]
+        x = _chan(np.concatenate(parts), 0.02 * (trial - 2), 0.4 * trial, 12.0, rng)
+        of = oracle_frames(oracle, x)
+        for seg in (0, 16384):
+            ctx = fx.RxContext(1, want_framesyms=True, segment_len=seg)
+            compare_frames(of, ctx.process([x]))
+            tm = ctx.timing(); failures += tm["verify_failures"]; hops += tm["verify_hops"]
+            ctx.close()
+    assert hops > 0, "no hop was ever re-checked: skipping is not active"
+    assert failures > 0, "the fallback walk was never exercised by these inputs"
