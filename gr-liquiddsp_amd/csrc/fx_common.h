@@ -31,12 +31,21 @@
 #define FX_SYM0_HDR      78      /* 2m + 64 */
 #define FX_SYM0_PAY      309
 
-// waves per walker workgroup (build-time: 4 or 8).  8 halves the latency of a detector hop (49 CFO-sweep
-// transforms in 7 rounds instead of 13) at one workgroup per CU; 4 leaves room for two per CU.
-#ifndef FX_WALK_WAVES
-#define FX_WALK_WAVES 8
+// Waves per workgroup of the detector kernels (4 or 8).  8 halves the latency of a detector hop (49 CFO-sweep
+// transforms in 7 rounds instead of 13): right for the dense detector-only walker.  The flex_rx
+// walker spends most of its time in short serial phases at 256 VGPRs per wave; with 4 waves a workgroup holds half
+// a CU's register file instead of all of it, and payload waves of the blocks in flight fit beside it (measured:
+// +9 % throughput with blocks in flight, same latency alone).  The seek verifier has no serial chain to shorten;
+// small workgroups pack better.
+#ifndef FX_FLEX_WAVES
+#define FX_FLEX_WAVES 4
 #endif
-#define FX_WALK_THREADS (64 * FX_WALK_WAVES)
+#ifndef FX_DETECT_WAVES
+#define FX_DETECT_WAVES 8
+#endif
+#ifndef FX_VERIFY_WAVES
+#define FX_VERIFY_WAVES 4
+#endif
 
 // header-stored enums (liquid.h v1.3.x numbering, recalled; see include/fxrx.h)
 enum { FX_CRC_UNKNOWN = 0, FX_CRC_NONE, FX_CRC_CHECKSUM, FX_CRC_8, FX_CRC_16, FX_CRC_24, FX_CRC_32 };

@@ -238,7 +238,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_PLL_STAGGER")) c->pll_stagger = (unsigned)std::min(256, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_DEC_WAVES")) c->dec_waves = (unsigned)std::min(8, std::max(1, std::atoi(e)));
     {
-        // The walker fills every CU it may use (8 waves x 256 VGPRs = one register file).  Keeping it off a few CUs
+        // Two flex_rx walker workgroups (4 waves x 256 VGPRs each) fill a CU's register file.  Keeping the walker off a few CUs
         // (FXRX_WALK_CUS=<n>; bench.py uses 224 of 256) leaves room where the latency-critical PLL / decode
         // waves of the blocks in flight always find a slot at once.
         hipDeviceProp_t prop; int ncu = 256;
@@ -262,9 +262,12 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
         const char *e = std::getenv("FXRX_PAYLOAD_SPLIT");
         int ncu = 256; hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) ncu = prop.multiProcessorCount;
-        const bool split = e && std::atoi(e) != 0 && c->n_cus < ncu;
+        bool split = e && std::atoi(e) != 0 && c->n_cus < ncu;
+        int first = c->n_cus;
+        // FXRX_RESERVE_CUS=<r>: payload streams stay off the first r CUs, which the (unmasked) walker then always finds empty
+        if (const char *r = std::getenv("FXRX_RESERVE_CUS")) { const int v = std::atoi(r); if (v > 0 && v < ncu) { split = true; first = v; } }
         std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-        for (int i = c->n_cus; i < ncu; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
+        for (int i = first; i < ncu; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
         for (unsigned i = 0; i < c->n_pstreams; i++) {
             const hipError_t err = split ? hipExtStreamCreateWithCUMask(&c->stream_p[i], (uint32_t)mask.size(), mask.data())
                                          : hipStreamCreateWithFlags(&c->stream_p[i], hipStreamNonBlocking);
@@ -314,7 +317,7 @@ void fxrx_reset(fxrx_ctx *c)
 
 int fxrx_set_depth(fxrx_ctx *c, unsigned int depth)
 {
-    if (!c || depth == 0 || depth > 8) return FXRX_ERR_ARG;
+    if (!c || depth == 0 || depth > 16) return FXRX_ERR_ARG;
     if (c->inflight) { set_err("fxrx_set_depth: blocks in flight"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
     while (c->slots.size() < depth) if (make_slot(c) != 0) return FXRX_ERR_HIP;
@@ -366,10 +369,10 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     uint64_t seg = c->cfg.segment_len;
     if (seg == 0) {
         uint64_t tot = 0; for (unsigned s = 0; s < NS; s++) tot += (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
-        // Walker workgroups resident at once: one per CU for the flex_rx instance (8 waves x 256 VGPRs), two for the
+        // Walker workgroups resident at once: two per CU for the flex_rx instance (4 waves x 256 VGPRs each), two for the
         // leaner detector-only instance.  Little work: a single round of workgroups with a small margin (the kernel
         // then lasts as long as its slowest segment).  Lots of work: ~4 rounds so that uneven segments even out.
-        const uint64_t slots = (uint64_t)c->n_cus * (FX_WALK_WAVES == 8 ? (detect ? 2u : 1u) : 2u);
+        const uint64_t slots = (uint64_t)c->n_cus * 2u;
         if (tot / slots < 131072) seg = tot / (slots - slots / 16);
         else seg = std::max<uint64_t>(tot / (4 * slots), 65536);
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);

@@ -23,33 +23,32 @@
 
 // 8 waves: the 49 CFO-sweep transforms of a hop take 7 rounds instead of 13.  The 512-sample window is still
 // handled by the first 256 threads (HALF); reductions keep the 4-wave tree order of the canonical arithmetic.
-#define WALK_THREADS FX_WALK_THREADS
-#define WALK_WAVES   FX_WALK_WAVES
 #define HALF         256
 
-struct WalkLds {
+template <int WW> struct WalkLdsT {
+    static constexpr int WAVES = WW;
     float2 win[FX_NFFT];            // time window of the current hop / aligned window
     float2 X[FX_NFFT];              // its spectrum
     float2 S[FX_NFFT];              // template spectrum
-    float2 scr[WALK_WAVES][576];    // per-wave FFT exchange buffers
+    float2 scr[WW][576];            // per-wave FFT exchange buffers
     float2 v[640];                  // mixed-down samples of the preamble+header span
     float2 P[256];                  // x conj(s) products (ALIGN)
     float  m2[FX_NFFT];
     float2 hdr[FX_HDR_SYM];
-    float2 cw[9 * FX_HOP + 8];      // coarse pre-lock scan: overlap half + eight new hops
+    float2 cw[(WW + 1) * FX_HOP + 8];   // coarse scan: overlap half + one new hop per wave
     float2 pb[16];                  // de-rotated pilots
     float  taps[FX_MF_TAPS];
-    float  redf[WALK_WAVES]; float2 redc[WALK_WAVES];
-    float  redv[WALK_WAVES]; uint32_t redk[WALK_WAVES];
+    float  redf[WW < 4 ? 4 : WW]; float2 redc[WW < 4 ? 4 : WW];
+    float  redv[WW]; uint32_t redk[WW];
     float  f[16];                   // scalar broadcast slots
     uint32_t u[16];
-    uint32_t cand[WALK_WAVES];
+    uint32_t cand[WW];
     uint8_t hs[FX_HDR_MOD];
     uint8_t b0[64], b1[64];
 };
 
 // ---- workgroup reductions (all 256 threads call; result on every thread) ----
-__device__ __forceinline__ float block_sum256(float v, WalkLds &L, int lane, int wave)
+template <class LDS> __device__ __forceinline__ float block_sum256(float v, LDS &L, int lane, int wave)
 {
     v = wave_sum(v);                       // callers pass 0 from threads >= HALF; only waves 0-3 enter the tree
     __syncthreads();
@@ -57,7 +56,7 @@ __device__ __forceinline__ float block_sum256(float v, WalkLds &L, int lane, int
     __syncthreads();
     return (L.redf[0] + L.redf[1]) + (L.redf[2] + L.redf[3]);
 }
-__device__ __forceinline__ float2 block_csum256(float2 v, WalkLds &L, int lane, int wave)
+template <class LDS> __device__ __forceinline__ float2 block_csum256(float2 v, LDS &L, int lane, int wave)
 {
     v.x = wave_sum(v.x); v.y = wave_sum(v.y);
     __syncthreads();
@@ -83,7 +82,7 @@ __device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_,
 // published by a barrier), x2_0 / x2_1 the energies of its halves.  Forward FFT, 49-bin CFO sweep, first maximum in
 // (bin, lag) order.  Shared by the walker and by fx_seekverify_kernel so that both take bit-identical decisions.
 // Called by the whole workgroup; result on every thread.
-__device__ __forceinline__ bool seek_sweep(WalkLds &L, float x2_0, float x2_1, float threshold, float s2sum, const float2 (&twA)[7],
+template <class LDS> __device__ __forceinline__ bool seek_sweep(LDS &L, float x2_0, float x2_1, float threshold, float s2sum, const float2 (&twA)[7],
                                            const float2 (&twB)[7], int lane, int wave, uint32_t &bidx, int &boff, float &peak)
 {
     const float g0 = sqrtf(x2_0 + x2_1) * sqrtf((float)FX_S_LEN / (float)FX_NFFT);
@@ -101,7 +100,7 @@ __device__ __forceinline__ bool seek_sweep(WalkLds &L, float x2_0, float x2_1, f
     __syncthreads();
     // CFO sweep: offsets -24..24 dealt round-robin to the waves
     float bv = -1.0f; uint32_t bk = 0xFFFFFFFFu;
-    for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += WALK_WAVES) {
+    for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += LDS::WAVES) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int i = lane + 64 * q;
@@ -123,7 +122,7 @@ __device__ __forceinline__ bool seek_sweep(WalkLds &L, float x2_0, float x2_1, f
     __syncthreads();
     bv = L.redv[0]; bk = L.redk[0];
 #pragma unroll
-    for (int w = 1; w < WALK_WAVES; w++) {
+    for (int w = 1; w < LDS::WAVES; w++) {
         float ov = L.redv[w]; uint32_t ok = L.redk[w];
         bool take = (ov > bv) || (ov == bv && ok < bk);
         bv = take ? ov : bv; bk = take ? ok : bk;
@@ -137,7 +136,7 @@ __device__ __forceinline__ bool seek_sweep(WalkLds &L, float x2_0, float x2_1, f
 // header: 54 received bytes (L.b0) -> 20 header bytes (L.b1[0..19]) + CRC verdict (L.u[1]).
 // Called by the whole workgroup; every stage is spread over threads (a one-thread version of this cost more
 // than the rest of the header span together).
-__device__ __forceinline__ void decode_header_bytes(WalkLds &L, const FxTables *T, int tid)
+template <class LDS> __device__ __forceinline__ void decode_header_bytes(LDS &L, const FxTables *T, int tid)
 {
     uint8_t *b0 = L.b0, *b1 = L.b1;
     auto gather_byte = [&](const uint8_t *src, const uint16_t *perm, int j) -> uint8_t {
@@ -193,11 +192,15 @@ __device__ __forceinline__ void decode_header_bytes(WalkLds &L, const FxTables *
 #ifndef FX_DETECT_OCC
 #define FX_DETECT_OCC 4      // waves per SIMD the detector-only instance is compiled for (2 or 4)
 #endif
-template <int MODE>
-__global__ __launch_bounds__(WALK_THREADS, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : 2)
+#ifndef FX_FLEX_OCC
+#define FX_FLEX_OCC 2        // same for the flex_rx instance
+#endif
+template <int MODE, int WW>
+__global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
 void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, const FxTables *T)
 {
-    __shared__ WalkLds L;
+    constexpr int WALK_WAVES = WW, WALK_THREADS = 64 * WW;
+    __shared__ WalkLdsT<WW> L;
     const FxWalkJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float2 *x = job.x;
@@ -657,8 +660,8 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, FxWalkResult *results,
                                      FxFrame *frames, const FxTables *T)
 {
-    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL(fx_walk_kernel<FX_MODE_DETECT>, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, frames, T);
-    else hipLaunchKernelGGL(fx_walk_kernel<FX_MODE_FLEXRX>, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, frames, T);
+    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_DETECT, FX_DETECT_WAVES>), dim3(njobs), dim3(64 * FX_DETECT_WAVES), 0, st, jobs, results, frames, T);
+    else hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, results, frames, T);
     return hipGetLastError();
 }
 
@@ -666,10 +669,12 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t 
 // A run of consecutive hops of the exact detector, all expected to come up empty (the hops a locked walker skipped
 // on the strength of its coarse scan).  Hops are independent given (pos, floor), so the runs are cut to spread over
 // the whole chip; the workgroup slides its window exactly like the walker does.
-__global__ __launch_bounds__(WALK_THREADS, FX_DETECT_OCC)
+template <int WW>
+__global__ __launch_bounds__(64 * WW, FX_DETECT_OCC)
 void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
 {
-    __shared__ WalkLds L;
+    constexpr int WALK_THREADS = 64 * WW;
+    __shared__ WalkLdsT<WW> L;
     const FxVerifyJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 twA[7], twB[7];
@@ -702,7 +707,7 @@ void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, cons
 
 extern "C" hipError_t fx_launch_seekverify(unsigned njobs, hipStream_t st, const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
 {
-    hipLaunchKernelGGL(fx_seekverify_kernel, dim3(njobs), dim3(WALK_THREADS), 0, st, jobs, results, T);
+    hipLaunchKernelGGL(fx_seekverify_kernel<FX_VERIFY_WAVES>, dim3(njobs), dim3(64 * FX_VERIFY_WAVES), 0, st, jobs, results, T);
     return hipGetLastError();
 }
 
@@ -1010,36 +1015,48 @@ __device__ __forceinline__ void block_fec_decode(unsigned fs, uint32_t n, const 
 // operations, no ds_bpermute.  Metrics, tie rule (equal -> predecessor with MSB 0) and traceback are the
 // plain algorithm's; only the lane numbering rotates.
 //   enc: coded bits (punctured stream), dec: n bytes, dw: T = 8n+6 decision words of scratch.
-template <int PH> __device__ __forceinline__ uint32_t lane_xor(uint32_t v, int lane)
+// One add-compare-select step at rotation phase PH.  Metrics are kept doubled (P = 2*metric, even) so that a
+// parity tag can break ties and carry the decision.  Every lane forms two keys from its own metric,
+//   key of its own branch          K = P + 2*bm + hi            (hi = MSB of the state this lane holds), and
+//   key of the branch to the partner's successor   X = P + 2*(nbits - bm) + hi
+// (both generator polynomials have their end taps set, so the cross branch expects the complement), ships X to
+// the butterfly partner and keeps min(K, X of the partner).  The keys never tie, the smaller wins with "equal
+// metrics -> predecessor with MSB 0", and its LSB -- the MSB of the state it came from -- is the decision bit.
+//
+// Exchange: phases 2-5 are DPP row operations folded into the min.  For phases 0 / 1 (xor 32 / xor 16) the lanes
+// with hi = 1 form their two keys in swapped roles (A = X, B = K; their expected code bits are stored
+// complemented for that), so that one permlane swap of (A, B) leaves min(A', B') = the wanted minimum in every
+// lane -- no copies, no select.
+//   tab: !PUNCT: ta[PH] / tb[PH] hold the four possible key increments (byte r = received pair ra | rb << 1);
+//        PUNCT:  ta[PH] = expected code bits (bit-doubled, role-adjusted), tb[PH] = 2 * hi.
+template <int PH>
+__device__ __forceinline__ uint32_t acs_exchange_min(uint32_t A, uint32_t B)
 {
-    if constexpr (PH == 0) { auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); return (lane & 32) ? r[0] : r[1]; }
-    else if constexpr (PH == 1) { auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); return (lane & 16) ? r[0] : r[1]; }
-    else if constexpr (PH == 2) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, false), 0x141, 0xf, 0xf, false);
-    else if constexpr (PH == 3) return __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false);
-    else if constexpr (PH == 4) return __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, false);
-    else return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, false);
+    if constexpr (PH == 0) { auto r = __builtin_amdgcn_permlane32_swap(A, B, false, false); return min(r[0], r[1]); }
+    else if constexpr (PH == 1) { auto r = __builtin_amdgcn_permlane16_swap(A, B, false, false); return min(r[0], r[1]); }
+    else if constexpr (PH == 2) return min(A, (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)B, 0x140, 0xf, 0xf, false), 0x141, 0xf, 0xf, false));
+    else if constexpr (PH == 3) return min(A, (uint32_t)__builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int)B, 0x141, 0xf, 0xf, false), 0x1B, 0xf, 0xf, false));
+    else if constexpr (PH == 4) return min(A, (uint32_t)__builtin_amdgcn_mov_dpp((int)B, 0x4E, 0xf, 0xf, false));
+    else return min(A, (uint32_t)__builtin_amdgcn_mov_dpp((int)B, 0xB1, 0xf, 0xf, false));
 }
 
-// One add-compare-select step at rotation phase PH.  Metrics are kept doubled (P = 2*metric, even) so that a
-// parity tag can break ties and carry the decision: own key = P + 2*bm_own + hi, partner key = P' + 2*bm_oth
-// + (1 - hi); the keys never tie, the smaller wins with "equal metrics -> predecessor with MSB 0", and its
-// LSB is the decision bit (1 = survivor came from the MSB-1 predecessor).  2*bm comes from one popcount of
-// (expected ^ received) on bit-doubled code bits; the partner's branch expects the complement (both
-// generator polynomials have their end taps set), so 2*bm_oth = 2*nbits - 2*bm_own.
 template <int PH, bool PUNCT>
-__device__ __forceinline__ void acs_step(uint32_t &P, unsigned code, uint32_t u, const unsigned (&eown)[6], int lane, unsigned &hist)
+__device__ __forceinline__ void acs_step(uint32_t &P, unsigned cu, const unsigned (&ta)[6], const unsigned (&tb)[6], int lane, unsigned &hist)
 {
-    const unsigned cu = (unsigned)__builtin_amdgcn_readlane((int)code, (int)u);       // R4 | H4<<4 | (2*nbits)<<8
-    const unsigned hi = ((unsigned)lane >> (5 - PH)) & 1u;
-    unsigned t = eown[PH] ^ (cu & 15u);
-    unsigned nb2 = 4u;
-    if constexpr (PUNCT) { t &= (cu >> 4) & 15u; nb2 = cu >> 8; }
-    const unsigned q = __popc(t);                                                      // 2 * bm_own
-    const uint32_t x = (nb2 + 1u - hi) - q;                                            // off the metric's critical path
-    const uint32_t Po = lane_xor<PH>(P, lane);
-    const uint32_t k_own = P + (q + hi);
-    const uint32_t k_oth = Po + x;
-    const uint32_t m = min(k_own, k_oth);
+    // cu: this step's received code word, already in a scalar register -- PUNCT: R4 | H4<<4 | (2*nbits)<<8, else 8*r
+    uint32_t A, B;
+    if constexpr (PUNCT) {
+        const unsigned hi = ((unsigned)lane >> (5 - PH)) & 1u;
+        const unsigned t = (ta[PH] ^ (cu & 15u)) & ((cu >> 4) & 15u);
+        const unsigned a = __popc(t) + hi;                                             // 2 * bm (role-adjusted) + hi
+        const unsigned b = ((cu >> 8) & 15u) - a;                                      // off the metric's critical path
+        A = P + a;
+        B = P + b + tb[PH];
+    } else {
+        A = P + __builtin_amdgcn_ubfe(ta[PH], cu, 8u);
+        B = P + __builtin_amdgcn_ubfe(tb[PH], cu, 8u);
+    }
+    const uint32_t m = acs_exchange_min<PH>(A, B);
     hist = (hist << 1) | (m & 1u);
     P = m & ~1u;
 }
@@ -1051,15 +1068,27 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
     unsigned long long tv0_ = __builtin_readcyclecounter();
 #endif
     const uint32_t Tn = 8 * n + 6;
-    // bit-doubled expected code bits (A in bits 0-1, B in bits 2-3) of the branch that ends in this lane's own
-    // predecessor role, for each rotation phase
-    unsigned eown[6];
+    // per rotation phase: this lane's state, its MSB (hi), the bit-doubled expected code bits of its own branch
+    // (A in bits 0-1, B in bits 2-3), role-adjusted for the swap phases -- see acs_step
+    unsigned ta[6], tb[6];
 #pragma unroll
     for (int ph = 0; ph < 6; ph++) {
         const unsigned st = (((unsigned)lane << ph) | ((unsigned)lane >> (6 - ph))) & 63u;   // state held at phase ph
-        const unsigned b = st >> 5;                                                           // = hi: this lane is the MSB-1 side
-        const unsigned sr = ((st << 1) | b) & 0x7f;                                           // own branch: (st) -> rotl(st,1)
-        eown[ph] = ((__popc(sr & 0x6d) & 1) ? 3u : 0u) | ((__popc(sr & 0x4f) & 1) ? 12u : 0u);
+        const unsigned hi = st >> 5;                                                          // this lane is the MSB-1 side
+        const unsigned sr = ((st << 1) | hi) & 0x7f;                                          // own branch: (st) -> rotl(st,1)
+        unsigned e = ((__popc(sr & 0x6d) & 1) ? 3u : 0u) | ((__popc(sr & 0x4f) & 1) ? 12u : 0u);
+        if (ph < 2 && hi) e ^= 15u;                                                           // swapped roles: A = cross key
+        if (PUNCT) { ta[ph] = e; tb[ph] = 2u * hi; }
+        else {
+            unsigned wa = 0, wb = 0;
+#pragma unroll
+            for (unsigned r = 0; r < 4; r++) {
+                const unsigned R4 = ((r & 1u) ? 3u : 0u) | ((r & 2u) ? 12u : 0u);
+                const unsigned a = __popc(e ^ R4) + hi;
+                wa |= a << (8 * r); wb |= (4u + 2u * hi - a) << (8 * r);
+            }
+            ta[ph] = wa; tb[ph] = wb;
+        }
     }
     unsigned pa, pb;                                       // puncturing rows (A, B) as bit masks over the column
     switch (p) {
@@ -1080,6 +1109,7 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
         unsigned ra = 0, rb = 0;
         if (hasA) { ra = getbit(enc, nb); nb++; }
         if (hasB) { rb = getbit(enc, nb); }
+        if (!PUNCT) return 8u * (ra | (rb << 1));
         return (ra * 3u) | (rb * 12u) | ((hasA * 3u | hasB * 12u) << 4) | ((2u * (hasA + hasB)) << 8);
     };
     uint32_t P = (lane == 0) ? 0u : (1u << 25);            // state 0 sits in lane 0 at every phase
@@ -1093,21 +1123,25 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
         for (int h = 0; h < 2; h++) {
             const uint32_t ub = 32u * h, ue = min(nstep, ub + 32u);
             uint32_t u = ub;
+            // the code words travel lane -> scalar register; fetch a whole group of six before its first step, so that the
+            // VALU -> SGPR -> operand latency of the fetch is off the metric chain
+            auto cw = [&](uint32_t uu) -> unsigned { return (unsigned)__builtin_amdgcn_readlane((int)code, (int)uu); };
             while (u < ue) {
                 switch ((t0 + u) % 6) {
                 case 0:
                     if (u + 6 <= ue) {
-                        acs_step<0, PUNCT>(P, code, u, eown, lane, hist[h]);     acs_step<1, PUNCT>(P, code, u + 1, eown, lane, hist[h]);
-                        acs_step<2, PUNCT>(P, code, u + 2, eown, lane, hist[h]); acs_step<3, PUNCT>(P, code, u + 3, eown, lane, hist[h]);
-                        acs_step<4, PUNCT>(P, code, u + 4, eown, lane, hist[h]); acs_step<5, PUNCT>(P, code, u + 5, eown, lane, hist[h]);
+                        const unsigned c0 = cw(u), c1 = cw(u + 1), c2 = cw(u + 2), c3 = cw(u + 3), c4 = cw(u + 4), c5 = cw(u + 5);
+                        acs_step<0, PUNCT>(P, c0, ta, tb, lane, hist[h]); acs_step<1, PUNCT>(P, c1, ta, tb, lane, hist[h]);
+                        acs_step<2, PUNCT>(P, c2, ta, tb, lane, hist[h]); acs_step<3, PUNCT>(P, c3, ta, tb, lane, hist[h]);
+                        acs_step<4, PUNCT>(P, c4, ta, tb, lane, hist[h]); acs_step<5, PUNCT>(P, c5, ta, tb, lane, hist[h]);
                         u += 6;
-                    } else { acs_step<0, PUNCT>(P, code, u, eown, lane, hist[h]); u++; }
+                    } else { acs_step<0, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; }
                     break;
-                case 1: acs_step<1, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
-                case 2: acs_step<2, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
-                case 3: acs_step<3, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
-                case 4: acs_step<4, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
-                default: acs_step<5, PUNCT>(P, code, u, eown, lane, hist[h]); u++; break;
+                case 1: acs_step<1, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 2: acs_step<2, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 3: acs_step<3, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 4: acs_step<4, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                default: acs_step<5, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
                 }
             }
         }

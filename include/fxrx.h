@@ -159,7 +159,7 @@ int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out);
 
 /* Pipelined form of fxrx_process (= submit + collect).  fxrx_submit walks the block (it returns once the
  * frames are located and the payload stages are queued), fxrx_collect waits for the OLDEST submitted block
- * and exposes its results through fxrx_result / fxrx_last_timing.  With depth d (fxrx_set_depth, 1..8, default
+ * and exposes its results through fxrx_result / fxrx_last_timing.  With depth d (fxrx_set_depth, 1..16, default
  * 1) up to d blocks may be in flight: the walk of block n+1, the payload PLL of block n and the packet decode
  * of block n-1 then overlap on three HIP streams.  Blocks of one stream must still be submitted in order;
  * device input buffers must stay valid until their block has been collected; results stay valid until the
