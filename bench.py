@@ -26,10 +26,9 @@ sys.path.insert(0, ROOT)
 
 # Runtime knobs, set before anything initialises HIP.  The pipeline keeps several blocks in flight on separate HIP
 # streams; HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them torch's), and
-# streams that share a queue serialise.  Eight queues let the walker stream and six payload streams run concurrently.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "6")
-os.environ.setdefault("FXRX_WALK_CUS", "224")      # walker kept off 32 CUs: PLL / decode waves of blocks in flight start at once
+# streams that share a queue serialise.  Twelve queues let the two walk streams and eight payload streams (one per block in flight) run concurrently.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
+os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "8")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 N_SAMPLES = 20_000_000         # 10 Msym at k = 2 samples/symbol
@@ -150,7 +149,7 @@ def main():
     depth = 1 if a.no_pipeline else a.depth
     ctx.set_depth(depth)
 
-    kt_live = dict(walk_ms=0.0, seekverify_ms=0.0, paymf_ms=0.0, paypll_ms=0.0, paydec_ms=0.0, host_submit_ms=0.0, host_walkwait_ms=0.0)
+    kt_live = dict(walk_ms=0.0, seekverify_ms=0.0, paymf_ms=0.0, paypll_ms=0.0, paydec_ms=0.0, host_submit_ms=0.0, host_walkwait_ms=0.0, host_collectwait_ms=0.0)
 
     def collect():
         n = ctx.collect_raw()
@@ -205,7 +204,8 @@ def main():
             "kernels_ms": {names[k]: round(live[k], 4) for k in names},
             "kernels_ms_one_block_in_flight": {names[k]: round(kt[k], 4) for k in names},
             "device_ms_per_step": round(kt["total_ms"], 4),
-            "host_ms_per_step": {"in_submit": round(live["host_submit_ms"], 4), "of_which_waiting_for_walker": round(live["host_walkwait_ms"], 4)},
+            "host_ms_per_step": {"in_submit": round(live["host_submit_ms"], 4), "of_which_waiting_for_walker": round(live["host_walkwait_ms"], 4),
+                                 "in_collect_waiting_for_results": round(live["host_collectwait_ms"], 4)},
             "whole_path_hbm_gbs": round(alg_bytes / (dt / a.steps) / 1e9, 2),
         }
         if world == 1 and not a.no_cpu_baseline:

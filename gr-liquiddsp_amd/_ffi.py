@@ -55,7 +55,8 @@ class Timing(C.Structure):                  # fxrx_timing
                 ("hops", C.c_uint64), ("walk_jobs", C.c_uint64), ("repairs", C.c_uint64),
                 ("frames", C.c_uint64), ("payload_symbols", C.c_uint64), ("samples", C.c_uint64), ("hops_cheap", C.c_uint64),
                 ("host_submit_ms", C.c_double), ("host_walkwait_ms", C.c_double),
-                ("seekverify_ms", C.c_double), ("verify_hops", C.c_uint64), ("verify_failures", C.c_uint64)]
+                ("seekverify_ms", C.c_double), ("verify_hops", C.c_uint64), ("verify_failures", C.c_uint64),
+                ("host_collectwait_ms", C.c_double)]
 
 
 # every symbol include/fxrx.h declares (checked by tests/test_cabi.py)

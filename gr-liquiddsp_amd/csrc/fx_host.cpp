@@ -103,6 +103,19 @@ struct Slot {
     hipEvent_t ev_mf0 = nullptr, ev_mf1 = nullptr, ev_pll0 = nullptr, ev_pll1 = nullptr, ev_dec0 = nullptr, ev_dec1 = nullptr, ev_done = nullptr;
     hipStream_t stream_p = nullptr, stream_d = nullptr;   // borrowed from the context (see fxrx_ctx_s)
     bool busy = false;
+    // walk stage.  Per block, because the walk of a block may be launched before the previous block's walk has been
+    // stitched (see fxrx_submit): job descriptors, results and frame tables are pinned host memory the kernels address
+    // directly; xs / ns / first_job / NJ are what the completion phase needs to know about the launch.
+    std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
+    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames; PinBuf<FxWalkJob> hp_jobs;
+    PinBuf<FxVerifyJob> hp_vjobs; PinBuf<FxVerifyResult> h_vres;
+    hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr, ev_v0 = nullptr, ev_v1 = nullptr, ev_carry = nullptr;
+    unsigned index = 0;                  // position in the ring of slots
+    hipStream_t stream_w = nullptr;      // the walk stream this block uses (borrowed)
+    std::vector<const float2 *> xs; std::vector<int64_t> ns; std::vector<size_t> first_job;
+    size_t NJ = 0; uint32_t repair_base = 0, repair_cap = 256;
+    uint64_t epoch = 0;                  // fxrx_reset generation the block was submitted in
+    bool walking = false;                // walk launched, completion phase (stitch .. payload launch) still to run
 };
 
 struct fxrx_ctx_s {
@@ -116,15 +129,13 @@ struct fxrx_ctx_s {
     unsigned pll_waves = 1, dec_waves = 1;   // waves per workgroup of the PLL / decode grids (placement only)
     unsigned pll_stagger = 32;               // blocks in flight start their PLL grids this many workgroup slots apart (0 = off)
     int n_cus = 256;
-    hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr;
+    hipStream_t stream2 = nullptr;       // second walk stream: consecutive independent blocks alternate (see fxrx_submit)
+    bool early_walk = true;              // FXRX_EARLY_WALK=0: never launch a walk before the previous block is stitched
+    uint64_t epoch = 0;     // fxrx_reset generation; blocks submitted so far
+    struct Slot *pending = nullptr;      // the block whose walk is launched but not yet stitched (at most one)
     hipEvent_t ev_last_mf = nullptr;     // end of the most recent payload MF (borrowed from its slot): guards the work buffers
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
-    // walker (host-synchronised per submit, so one set suffices)
-    std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
-    PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames; PinBuf<FxWalkJob> hp_jobs;   // device-visible (see launch_walk)
-    PinBuf<FxVerifyJob> hp_vjobs; PinBuf<FxVerifyResult> h_vres;                        // seek verification, likewise
-    hipEvent_t ev_v0 = nullptr, ev_v1 = nullptr;
     bool skip_seek = true;               // FXRX_SKIP_SEEK=0: walkers run the full detector on every hop (no verification pass)
     // packet plans (shared, append-only)
     std::map<PlanKey, PlanDev> plans; std::vector<uint32_t> perm_host; DevBuf<uint32_t> d_perm; size_t perm_uploaded = 0;
@@ -193,13 +204,13 @@ const PlanDev &get_plan(fxrx_ctx_s *c, unsigned n, unsigned check, unsigned fec0
 // slots continues through the FX_EXIT_TABLE_FULL path.
 inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 2048 + 8, 512); }
 
-int launch_walk(fxrx_ctx_s *c, size_t first, size_t count)
+int launch_walk(fxrx_ctx_s *c, Slot &sl, size_t first, size_t count)
 {
     // Job descriptors, per-job results and frame tables live in pinned host memory that the kernel addresses
     // directly: each workgroup reads one descriptor and writes a handful of 128-byte records, so the PCIe hop costs
     // less than the three staging copies it replaces on the walk -> stitch critical path.
-    std::memcpy(c->hp_jobs.p + first, c->jobs.data() + first, count * sizeof(FxWalkJob));
-    HIP_OK(fx_launch_walk(c->jobs[first].mode, (unsigned)count, c->stream, c->hp_jobs.p + first, c->h_res.p + first, c->h_frames.p, c->d_tables));
+    std::memcpy(sl.hp_jobs.p + first, sl.jobs.data() + first, count * sizeof(FxWalkJob));
+    HIP_OK(fx_launch_walk(sl.jobs[first].mode, (unsigned)count, sl.stream_w, sl.hp_jobs.p + first, sl.h_res.p + first, sl.h_frames.p, c->d_tables));
     return 0;
 }
 
@@ -215,8 +226,10 @@ int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess
 static int make_slot(fxrx_ctx_s *c)
 {
     std::unique_ptr<Slot> s(new Slot);
-    hipEvent_t *ev[7] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll0, &s->ev_pll1, &s->ev_dec0, &s->ev_dec1, &s->ev_done };
+    hipEvent_t *ev[12] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll0, &s->ev_pll1, &s->ev_dec0, &s->ev_dec1, &s->ev_done,
+                           &s->ev_w0, &s->ev_w1, &s->ev_v0, &s->ev_v1, &s->ev_carry };
     for (auto e : ev) HIP_OK(hipEventCreate(e));
+    s->index = (unsigned)c->slots.size();
     s->stream_p = c->stream_p[c->slots.size() % c->n_pstreams]; s->stream_d = s->stream_p;
     c->slots.push_back(std::move(s));
     return 0;
@@ -252,7 +265,11 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
             std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
             for (int i = 0; i < want; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
             err = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)mask.size(), mask.data());
-        } else err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+            if (err == hipSuccess) err = hipExtStreamCreateWithCUMask(&c->stream2, (uint32_t)mask.size(), mask.data());
+        } else {
+            err = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+            if (err == hipSuccess) err = hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+        }
         if (err != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
     }
     {
@@ -274,9 +291,8 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
             if (err != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
         }
     }
-    if (hipEventCreate(&c->ev_w0) != hipSuccess || hipEventCreate(&c->ev_w1) != hipSuccess ||
-        hipEventCreate(&c->ev_v0) != hipSuccess || hipEventCreate(&c->ev_v1) != hipSuccess) { set_err("hipEventCreate failed"); return nullptr; }
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_EARLY_WALK")) c->early_walk = std::atoi(e) != 0;
     if (upload_tables(c.get()) != 0) return nullptr;
     c->st.resize(cfg->n_streams);
     if (make_slot(c.get()) != 0) return nullptr;
@@ -286,6 +302,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
 static void sync_all(fxrx_ctx_s *c)
 {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->stream2) (void)hipStreamSynchronize(c->stream2);
     for (auto s : c->stream_p) if (s) (void)hipStreamSynchronize(s);
 }
 
@@ -295,23 +312,22 @@ void fxrx_destroy(fxrx_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     sync_all(c);
     for (auto &s : c->slots) {
-        hipEvent_t ev[7] = { s->ev_mf0, s->ev_mf1, s->ev_pll0, s->ev_pll1, s->ev_dec0, s->ev_dec1, s->ev_done };
+        hipEvent_t ev[12] = { s->ev_mf0, s->ev_mf1, s->ev_pll0, s->ev_pll1, s->ev_dec0, s->ev_dec1, s->ev_done, s->ev_w0, s->ev_w1, s->ev_v0, s->ev_v1, s->ev_carry };
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
     }
-    if (c->ev_w0) (void)hipEventDestroy(c->ev_w0);
-    if (c->ev_w1) (void)hipEventDestroy(c->ev_w1);
-    if (c->ev_v0) (void)hipEventDestroy(c->ev_v0);
-    if (c->ev_v1) (void)hipEventDestroy(c->ev_v1);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->stream2) (void)hipStreamDestroy(c->stream2);
     for (auto s : c->stream_p) if (s) (void)hipStreamDestroy(s);
     delete c;
 }
 
-// forget all per-stream state (position, carried tail).  In-flight blocks are unaffected.
+// forget all per-stream state (position, carried tail).  In-flight blocks are unaffected (a block submitted before
+// the reset no longer writes its resume state back: the epoch tells).
 void fxrx_reset(fxrx_ctx *c)
 {
     if (!c) return;
+    c->epoch++;
     for (auto &s : c->st) { s.carry_len = 0; s.base = 0; s.pos = 0; s.floor_ = 0; s.fresh = true; }
 }
 
@@ -336,31 +352,32 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
     return c->last->n_syms ? c->last->d_framesyms.p : nullptr;
 }
 
-int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
+// ---- phase 1 of a block: stage its input, cut it into segments, launch the walkers (nothing is waited for) ----
+static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint64_t *n_samples, int on_device)
 {
-    if (!c || !iq || !n_samples) { set_err("fxrx_submit: null argument"); return FXRX_ERR_ARG; }
-    if (c->inflight >= c->depth) { set_err("fxrx_submit: pipeline full, call fxrx_collect first"); return FXRX_ERR_STATE; }
-    HIP_OK(hipSetDevice(c->cfg.device));
-    Slot &sl = *c->slots[c->head];
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
     sl.out.clear(); sl.timing = fxrx_timing{};
-    for (auto &w : c->walk_stamp) w = 0;
-    c->walk_stamp_max = 0;
     const auto t_enter = std::chrono::steady_clock::now();
+    // Streams are tied to slots, not to blocks: the HIP runtime tracks which queue last touched a buffer that takes part
+    // in a hipMemcpyAsync and makes the next queue wait for the previous one, so handing a slot's arenas to a different
+    // stream every time serialises the payload stages (measured: 10.7 instead of 17.8 Gsamples/s).
+    sl.stream_w = (sl.index & 1u) ? c->stream2 : c->stream;
+    sl.epoch = c->epoch;
+    std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns; std::vector<size_t> &first_job = sl.first_job;
+    xs.assign(NS, nullptr); ns.assign(NS, 0); first_job.assign(NS + 1, 0);
 
     // ---- 1. per-stream work buffers: [tail of previous call | new samples] ----
-    std::vector<const float2 *> xs(NS); std::vector<int64_t> ns(NS);
     uint64_t total_new = 0;
     for (unsigned s = 0; s < NS; s++) {
         StreamState &S = c->st[s];
         const uint64_t nn = n_samples[s];
         total_new += nn;
         if (S.carry_len == 0 && on_device) { xs[s] = (const float2 *)iq[s]; ns[s] = (int64_t)nn; continue; }
-        if (c->ev_last_mf) { HIP_OK(hipStreamWaitEvent(c->stream, c->ev_last_mf, 0)); c->ev_last_mf = nullptr; }   // that MF reads S.work
+        if (c->ev_last_mf) { HIP_OK(hipStreamWaitEvent(sl.stream_w, c->ev_last_mf, 0)); c->ev_last_mf = nullptr; }   // that MF reads S.work
         if (S.work.reserve(S.carry_len + nn + 1)) return FXRX_ERR_HIP;
-        if (S.carry_len) HIP_OK(hipMemcpyAsync(S.work.p, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
-        if (nn) HIP_OK(hipMemcpyAsync(S.work.p + S.carry_len, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+        if (S.carry_len) HIP_OK(hipMemcpyAsync(S.work.p, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
+        if (nn) HIP_OK(hipMemcpyAsync(S.work.p + S.carry_len, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sl.stream_w));
         xs[s] = S.work.p; ns[s] = (int64_t)(S.carry_len + nn);
     }
     sl.timing.samples = total_new;
@@ -378,12 +395,11 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
     }
     seg = std::max<uint64_t>(seg, 4096);
-    c->jobs.clear(); c->job_stream.clear();
-    std::vector<size_t> first_job(NS + 1);
+    sl.jobs.clear(); sl.job_stream.clear();
     uint32_t frame_slots = 0;
     for (unsigned s = 0; s < NS; s++) {
         StreamState &S = c->st[s];
-        first_job[s] = c->jobs.size();
+        first_job[s] = sl.jobs.size();
         int64_t p = S.pos;
         bool first = true;
         while (first || p < ns[s]) {
@@ -400,28 +416,42 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
             j.no_skip = (detect || !c->skip_seek) ? 1u : 0u;
-            c->jobs.push_back(j); c->job_stream.push_back(s);
+            sl.jobs.push_back(j); sl.job_stream.push_back(s);
             p = j.stop; first = false;
             if (p >= ns[s]) break;
         }
     }
-    first_job[NS] = c->jobs.size();
-    const size_t NJ = c->jobs.size();
+    first_job[NS] = sl.jobs.size();
+    const size_t NJ = sl.jobs.size();
     // one spare job slot + frame region for repairs
-    const uint32_t repair_base = frame_slots; const uint32_t repair_cap = 256;
-    frame_slots += repair_cap;
-    if (c->h_res.reserve(NJ + 1) || c->hp_jobs.reserve(NJ + 1) || c->h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
-    c->jobs.resize(NJ + 1);
+    sl.NJ = NJ; sl.repair_base = frame_slots; sl.repair_cap = 256;
+    frame_slots += sl.repair_cap;
+    if (sl.h_res.reserve(NJ + 1) || sl.hp_jobs.reserve(NJ + 1) || sl.h_frames.reserve(frame_slots)) return FXRX_ERR_HIP;
+    sl.jobs.resize(NJ + 1);
+    HIP_OK(hipEventRecord(sl.ev_w0, sl.stream_w));
+    if (launch_walk(c, sl, 0, NJ)) return FXRX_ERR_HIP;
+    HIP_OK(hipEventRecord(sl.ev_w1, sl.stream_w));
+    sl.timing.walk_jobs = NJ;
+    sl.walking = true;
+    sl.timing.host_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    return 0;
+}
 
-    HIP_OK(hipEventRecord(c->ev_w0, c->stream));
-    if (launch_walk(c, 0, NJ)) return FXRX_ERR_HIP;
-    HIP_OK(hipEventRecord(c->ev_w1, c->stream));
+// ---- phase 2: wait for the walkers, stitch, verify the skipped hops, launch the payload stage, carry the tails ----
+static int complete_phase(fxrx_ctx_s *c, Slot &sl)
+{
+    const unsigned NS = c->cfg.n_streams;
+    const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
+    const auto t_enter = std::chrono::steady_clock::now();
+    std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns; std::vector<size_t> &first_job = sl.first_job;
+    const size_t NJ = sl.NJ; const uint32_t repair_base = sl.repair_base, repair_cap = sl.repair_cap;
+    for (auto &w : c->walk_stamp) w = 0;
+    c->walk_stamp_max = 0;
     {
         const auto tw = std::chrono::steady_clock::now();
-        HIP_OK(hipStreamSynchronize(c->stream));
+        HIP_OK(hipStreamSynchronize(sl.stream_w));
         sl.timing.host_walkwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
     }
-    sl.timing.walk_jobs = NJ;
 
     // ---- 3. stitch: per stream, splice speculative lists into the sequential chain ----
     // A chain also lists its seek spans: runs of hops [pos, end) on which the walkers reported no detection.  With
@@ -434,17 +464,17 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         ch.frames.clear(); ch.spans.clear();
         auto add_span = [&](int64_t p, int64_t fl, int64_t e) { if (e > p) ch.spans.push_back(Span{ p, fl, e }); };
         size_t cur = first_job[s]; uint32_t m = 0;
-        FxWalkResult R = c->h_res.p[cur]; const FxFrame *F = c->h_frames.p + c->jobs[cur].frame_base;
+        FxWalkResult R = sl.h_res.p[cur]; const FxFrame *F = sl.h_frames.p + sl.jobs[cur].frame_base;
         std::vector<FxFrame> repair_frames; float splice_rxy = -1.0f;
         bool spliced = false; int64_t tpos = 0, tfloor = 0; bool tfresh = true;   // true-chain state at the last splice
         auto run_repair = [&](const FxWalkJob &tmpl, const FxWalkResult &from) -> int {
             FxWalkJob j = tmpl; j.start = from.pos; j.fresh = from.fresh; j.floor = from.floor; j.prelock = 0;
             j.frame_base = repair_base; j.max_frames = repair_cap;
-            c->jobs[NJ] = j;
-            if (launch_walk(c, NJ, 1)) return FXRX_ERR_HIP;
-            HIP_OK(hipStreamSynchronize(c->stream));
+            sl.jobs[NJ] = j;
+            if (launch_walk(c, sl, NJ, 1)) return FXRX_ERR_HIP;
+            HIP_OK(hipStreamSynchronize(sl.stream_w));
             sl.timing.repairs++;
-            R = c->h_res.p[NJ]; repair_frames.assign(c->h_frames.p + repair_base, c->h_frames.p + repair_base + R.n_frames);
+            R = sl.h_res.p[NJ]; repair_frames.assign(sl.h_frames.p + repair_base, sl.h_frames.p + repair_base + R.n_frames);
             F = repair_frames.data(); m = 0;
             return 0;
         };
@@ -466,7 +496,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             const bool last = (cur + 1 == first_job[s + 1]);
             if (R.exit_code == FX_EXIT_TABLE_FULL) {                       // continue the same segment where the table filled up
                 const FxWalkResult from = R;
-                if (run_repair(c->jobs[cur], from)) return FXRX_ERR_HIP;
+                if (run_repair(sl.jobs[cur], from)) return FXRX_ERR_HIP;
                 continue;
             }
             if (last || R.exit_code != FX_EXIT_STOP || !R.has_handoff) {
@@ -481,8 +511,8 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             // hand-off: look the target up in the next segment's speculative list
             // (segments the true walker crossed without a detection cannot hold the target: skip them)
             size_t nxt = cur + 1;
-            while (nxt + 1 < first_job[s + 1] && R.handoff_start >= c->jobs[nxt].stop + FX_HOP) nxt++;
-            const FxWalkResult &RN = c->h_res.p[nxt]; const FxFrame *FN = c->h_frames.p + c->jobs[nxt].frame_base;
+            while (nxt + 1 < first_job[s + 1] && R.handoff_start >= sl.jobs[nxt].stop + FX_HOP) nxt++;
+            const FxWalkResult &RN = sl.h_res.p[nxt]; const FxFrame *FN = sl.h_frames.p + sl.jobs[nxt].frame_base;
             uint32_t found = UINT32_MAX;
             for (uint32_t i = 0; i < RN.n_frames; i++)
                 if ((FN[i].flags & FX_FLAG_EXACT) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; break; }
@@ -492,14 +522,14 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             }
             // repair: walk the next segment from the true state
             const FxWalkResult from = R;
-            if (run_repair(c->jobs[nxt], from)) return FXRX_ERR_HIP;
+            if (run_repair(sl.jobs[nxt], from)) return FXRX_ERR_HIP;
             cur = nxt;
         }
         return 0;
     };
     for (unsigned s = 0; s < NS; s++) if (stitch_stream(s)) return FXRX_ERR_HIP;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, c->ev_w0, c->ev_w1); sl.timing.walk_ms = ms;
+    (void)hipEventElapsedTime(&ms, sl.ev_w0, sl.ev_w1); sl.timing.walk_ms = ms;
 
     // ---- 3b. seek verification: the full detector over every hop the chains' walkers skipped ----
     if (!detect && c->skip_seek) {
@@ -520,31 +550,31 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             }
         sl.timing.verify_hops = tot_hops;
         if (!vj.empty()) {
-            if (c->hp_vjobs.reserve(vj.size()) || c->h_vres.reserve(vj.size())) return FXRX_ERR_HIP;
-            std::memcpy(c->hp_vjobs.p, vj.data(), vj.size() * sizeof(FxVerifyJob));
-            HIP_OK(hipEventRecord(c->ev_v0, c->stream));
-            HIP_OK(fx_launch_seekverify((unsigned)vj.size(), c->stream, c->hp_vjobs.p, c->h_vres.p, c->d_tables));
-            HIP_OK(hipEventRecord(c->ev_v1, c->stream));
+            if (sl.hp_vjobs.reserve(vj.size()) || sl.h_vres.reserve(vj.size())) return FXRX_ERR_HIP;
+            std::memcpy(sl.hp_vjobs.p, vj.data(), vj.size() * sizeof(FxVerifyJob));
+            HIP_OK(hipEventRecord(sl.ev_v0, sl.stream_w));
+            HIP_OK(fx_launch_seekverify((unsigned)vj.size(), sl.stream_w, sl.hp_vjobs.p, sl.h_vres.p, c->d_tables));
+            HIP_OK(hipEventRecord(sl.ev_v1, sl.stream_w));
             {
                 const auto tw = std::chrono::steady_clock::now();
-                HIP_OK(hipStreamSynchronize(c->stream));
+                HIP_OK(hipStreamSynchronize(sl.stream_w));
                 sl.timing.host_walkwait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
             }
-            (void)hipEventElapsedTime(&ms, c->ev_v0, c->ev_v1); sl.timing.seekverify_ms = ms;
+            (void)hipEventElapsedTime(&ms, sl.ev_v0, sl.ev_v1); sl.timing.seekverify_ms = ms;
             // A skipped hop on which the detector does fire (a false alarm, or a preamble too weak for the coarse
             // scan): that stream's chain is void from there on.  Walk the stream again with skipping off -- exact
             // by itself, as in the first version of this walker -- and stitch it again.
             std::vector<char> bad(NS, 0); unsigned n_bad = 0;
             for (size_t i = 0; i < vj.size(); i++)
-                if (c->h_vres.p[i].det_hop != 0xFFFFFFFFu && !bad[vj_stream[i]]) { bad[vj_stream[i]] = 1; n_bad++; }
+                if (sl.h_vres.p[i].det_hop != 0xFFFFFFFFu && !bad[vj_stream[i]]) { bad[vj_stream[i]] = 1; n_bad++; }
             if (n_bad) {
                 sl.timing.verify_failures = n_bad;
                 for (unsigned s = 0; s < NS; s++) {
                     if (!bad[s]) continue;
-                    for (size_t j = first_job[s]; j < first_job[s + 1]; j++) c->jobs[j].no_skip = 1u;
-                    if (launch_walk(c, first_job[s], first_job[s + 1] - first_job[s])) return FXRX_ERR_HIP;
+                    for (size_t j = first_job[s]; j < first_job[s + 1]; j++) sl.jobs[j].no_skip = 1u;
+                    if (launch_walk(c, sl, first_job[s], first_job[s + 1] - first_job[s])) return FXRX_ERR_HIP;
                 }
-                HIP_OK(hipStreamSynchronize(c->stream));
+                HIP_OK(hipStreamSynchronize(sl.stream_w));
                 for (unsigned s = 0; s < NS; s++) if (bad[s] && stitch_stream(s)) return FXRX_ERR_HIP;
             }
         }
@@ -641,7 +671,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         HIP_OK(hipEventRecord(sl.ev_pll0, sl.stream_p));
         // stagger concurrent blocks' PLL grids over different CUs (see the kernel): slot k skips k * (grid rounded to 32)
         const unsigned pll_wgs = (unsigned)((NP + 64 * c->pll_waves - 1) / (64 * c->pll_waves));
-        const unsigned wg_skip = (c->pll_stagger && pll_wgs <= 128) ? c->head * ((pll_wgs + c->pll_stagger - 1u) / c->pll_stagger * c->pll_stagger) : 0u;
+        const unsigned wg_skip = (c->pll_stagger && pll_wgs <= 128) ? sl.index * ((pll_wgs + c->pll_stagger - 1u) / c->pll_stagger * c->pll_stagger) : 0u;
         for (auto &g : groups)
             HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), wg_skip, c->pll_waves, sl.stream_p, d_pjobs, d_pll_idx + std::get<1>(g),
                                     sl.d_symraw.p, sl.d_framesyms.p, sl.d_hard.p, sl.d_pres.p, c->d_tables));
@@ -660,10 +690,11 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_framesyms.p, sym_total * sizeof(float2), hipMemcpyDeviceToHost, sl.stream_d));
         }
     }
-    HIP_OK(hipEventRecord(sl.ev_done, NP ? sl.stream_d : c->stream));
+    HIP_OK(hipEventRecord(sl.ev_done, NP ? sl.stream_d : sl.stream_w));
 
-    // ---- 5. carry the unconsumed tail of every stream into the next call (W, behind the MF) ----
-    for (unsigned s = 0; s < NS; s++) {
+    // ---- 5. carry the unconsumed tail of every stream into the next call (walk stream) ----
+    // (not if the streams were reset after this block was submitted: its resume state is nobody's business then)
+    for (unsigned s = 0; s < NS && sl.epoch == c->epoch; s++) {
         StreamState &S = c->st[s]; const Chain &ch = chains[s];
         int64_t keep_from = ch.fresh ? ch.pos : ch.pos - FX_HOP;
         keep_from = std::max<int64_t>(0, std::min<int64_t>(keep_from, ns[s]));
@@ -671,14 +702,35 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         const int nxt = S.cur ^ 1;
         if (keep) {
             if (S.carry[nxt].reserve(keep)) return FXRX_ERR_HIP;
-            HIP_OK(hipMemcpyAsync(S.carry[nxt].p, xs[s] + keep_from, keep * sizeof(float2), hipMemcpyDeviceToDevice, c->stream));
+            HIP_OK(hipMemcpyAsync(S.carry[nxt].p, xs[s] + keep_from, keep * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
         }
         S.cur = nxt; S.carry_len = keep; S.base += keep_from;
         S.pos = ch.pos - keep_from; S.floor_ = ch.floor_ - keep_from; S.fresh = ch.fresh;
     }
+    HIP_OK(hipEventRecord(sl.ev_carry, sl.stream_w));
+    sl.walking = false;
+    sl.timing.host_submit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    return 0;
+}
+
+// A block goes through walk_phase, then complete_phase.  The completion of block k needs the host (it stitches), and
+// the walk of block k+1 needs the stream state block k leaves behind -- unless the streams were reset in between
+// (independent captures, the bench's passes): then walk k+1 is launched first, on the other walk stream, and runs
+// while the host stitches / verifies / launches block k.  A continuing stream completes k before it walks k+1.
+int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
+{
+    if (!c || !iq || !n_samples) { set_err("fxrx_submit: null argument"); return FXRX_ERR_ARG; }
+    if (c->inflight >= c->depth) { set_err("fxrx_submit: pipeline full, call fxrx_collect first"); return FXRX_ERR_STATE; }
+    HIP_OK(hipSetDevice(c->cfg.device));
+    Slot &sl = *c->slots[c->head];
+    bool early = c->early_walk && c->pending != nullptr && on_device && c->pending->epoch != c->epoch;
+    for (const auto &S : c->st) if (S.carry_len != 0 || !S.fresh) early = false;
+    if (c->pending && !early) { Slot *p = c->pending; c->pending = nullptr; if (complete_phase(c, *p)) return FXRX_ERR_HIP; }
+    if (walk_phase(c, sl, iq, n_samples, on_device)) return FXRX_ERR_HIP;
+    if (c->pending) { Slot *p = c->pending; c->pending = nullptr; if (complete_phase(c, *p)) return FXRX_ERR_HIP; }
+    c->pending = &sl;
     sl.busy = true;
     c->head = (c->head + 1) % c->depth; c->inflight++;
-    sl.timing.host_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     return 0;
 }
 
@@ -688,8 +740,16 @@ int fxrx_collect(fxrx_ctx *c)
     if (!c->inflight) { set_err("fxrx_collect: nothing in flight"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
     Slot &sl = *c->slots[c->tail];
-    HIP_OK(hipEventSynchronize(sl.ev_done));
-    HIP_OK(hipStreamSynchronize(c->stream));       // tail-carry copies of this block (cheap; keeps caller buffers reusable)
+    if (sl.walking) {                                // the newest block: nobody has stitched it yet
+        if (c->pending == &sl) c->pending = nullptr;
+        if (complete_phase(c, sl)) return FXRX_ERR_HIP;
+    }
+    {
+        const auto tw = std::chrono::steady_clock::now();
+        HIP_OK(hipEventSynchronize(sl.ev_done));
+        HIP_OK(hipEventSynchronize(sl.ev_carry));
+        sl.timing.host_collectwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+    }      // tail-carry copies of this block (cheap; keeps caller buffers reusable)
     for (auto &o : sl.out) {
         if (o.pjob < 0) continue;
         const FxPayJob &j = sl.pjobs[(size_t)o.pjob]; const FxPayResult &r = sl.h_pres.p[o.pjob];

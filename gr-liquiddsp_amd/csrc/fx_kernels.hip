@@ -670,7 +670,7 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t 
 // on the strength of its coarse scan).  Hops are independent given (pos, floor), so the runs are cut to spread over
 // the whole chip; the workgroup slides its window exactly like the walker does.
 template <int WW>
-__global__ __launch_bounds__(64 * WW, FX_DETECT_OCC)
+__global__ __launch_bounds__(64 * WW, WW == 4 ? 3 : FX_DETECT_OCC)      // 4-wave workgroups: LDS allows three per CU
 void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
 {
     constexpr int WALK_THREADS = 64 * WW;

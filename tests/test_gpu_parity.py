@@ -351,3 +351,41 @@ def test_skipped_hops_are_verified_and_weak_preambles_fall_back(fx, oracle):
             ctx.close()
     assert hops > 0, "no hop was ever re-checked: skipping is not active"
     assert failures > 0, "the fallback walk was never exercised by these inputs"
+
+
+@pytest.mark.gpu
+def test_independent_captures_overlap_their_walks_exactly(fx, oracle):
+    """After fxrx_reset the next block does not depend on the one still being walked, so its walk is launched before
+    that one is stitched (two walk streams).  Different captures, device-resident, several in flight: every capture must
+    come out exactly as when processed alone, and a continuing stream (no reset) must still carry its state."""
+    import torch
+    caps = [fx.synth_stream(150_000 + 7_000 * i, stream_id=90 + i, payload_len=200 + 50 * i, mod=[2, 27, 3, 28][i % 4],
+                            fec0=[11, 15, 1, 17][i % 4])[0] for i in range(7)]
+    dev = [torch.from_numpy(c).cuda() for c in caps]
+    key = lambda g: (g["start"], g["payload"], g["payload_valid"], g["evm_sum"], g["rxy"])
+    alone = []
+    for c in caps:
+        ctx1 = fx.RxContext(1); alone.append([key(g) for g in ctx1.process([c])]); ctx1.close()
+    for i in (0, 3):
+        compare_frames(oracle_frames(oracle, caps[i]), fx.RxContext(1, want_framesyms=True).process([caps[i]]))
+    ctx = fx.RxContext(1)
+    ctx.set_depth(4)
+    got, inflight = [], 0
+    for d in dev:
+        if inflight == 4:
+            got.append([key(g) for g in ctx.results(ctx.collect_raw())]); inflight -= 1
+        ctx.reset()
+        ctx.submit_raw([d.data_ptr()], [d.numel()], True); inflight += 1
+    while inflight:
+        got.append([key(g) for g in ctx.results(ctx.collect_raw())]); inflight -= 1
+    assert got == alone
+    # the same context, now as one continuing stream cut in three (state must carry: no reset in between)
+    x = caps[2]; cuts = [0, 50_000, 101_234, len(x)]
+    ctx.reset()
+    parts = [torch.from_numpy(x[a:b].copy()).cuda() for a, b in zip(cuts[:-1], cuts[1:])]
+    cont = []
+    for p in parts:
+        ctx.submit_raw([p.data_ptr()], [p.numel()], True)
+    for _ in parts:
+        cont += [key(g) for g in ctx.results(ctx.collect_raw())]
+    assert cont == alone[2]
