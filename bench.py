@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 # Runtime knobs, set before anything initialises HIP.  The pipeline keeps several blocks in flight on separate HIP
 # streams; HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them torch's), and
-# streams that share a queue serialise.  Twelve queues let the two walk streams and eight payload streams (one per block in flight) run concurrently.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "8")
+# streams that share a queue serialise.  Sixteen queues let the two walk streams and ten payload streams (one per block in flight) run concurrently.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "10")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 N_SAMPLES = 20_000_000         # 10 Msym at k = 2 samples/symbol
@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--samples", type=int, default=N_SAMPLES)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one block in flight (latency mode)")
-    ap.add_argument("--depth", type=int, default=8, help="blocks in flight in the timed region")
+    ap.add_argument("--depth", type=int, default=10, help="blocks in flight in the timed region")
     ap.add_argument("--segment", type=int, default=0, help="speculation segment length in samples (0 = library default)")
     a = ap.parse_args()
 
@@ -145,7 +145,7 @@ def main():
     ok = check(nres)
 
     # timed region: K steps, each a full pass (reset + walk + MF + PLL + decode + results to the host), issued
-    # through the submit/collect pipeline (depth 3) the way a streaming receiver feeds consecutive blocks
+    # through the submit/collect pipeline the way a streaming receiver feeds consecutive blocks
     depth = 1 if a.no_pipeline else a.depth
     ctx.set_depth(depth)
 

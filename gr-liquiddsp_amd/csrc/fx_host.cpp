@@ -124,7 +124,7 @@ struct fxrx_ctx_s {
     // ones); streams that share a queue serialise.  So exactly three: W, and two payload streams used
     // alternately by consecutive blocks, each running its block's PLL -> decode -> result copies in order.
     hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
-    hipStream_t stream_p[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };   // payload PLL + packet decode, blocks round-robin
+    hipStream_t stream_p[16] = {};       // payload stage (MF -> PLL -> decode -> result copies), tied to the slots
     unsigned n_pstreams = 2;
     unsigned pll_waves = 1, dec_waves = 1;   // waves per workgroup of the PLL / decode grids (placement only)
     unsigned pll_stagger = 32;               // blocks in flight start their PLL grids this many workgroup slots apart (0 = off)
@@ -246,7 +246,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
-    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(8, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(16, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_PLL_WAVES")) c->pll_waves = (unsigned)std::min(4, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_PLL_STAGGER")) c->pll_stagger = (unsigned)std::min(256, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_DEC_WAVES")) c->dec_waves = (unsigned)std::min(8, std::max(1, std::atoi(e)));
@@ -671,7 +671,7 @@ static int complete_phase(fxrx_ctx_s *c, Slot &sl)
         HIP_OK(hipEventRecord(sl.ev_pll0, sl.stream_p));
         // stagger concurrent blocks' PLL grids over different CUs (see the kernel): slot k skips k * (grid rounded to 32)
         const unsigned pll_wgs = (unsigned)((NP + 64 * c->pll_waves - 1) / (64 * c->pll_waves));
-        const unsigned wg_skip = (c->pll_stagger && pll_wgs <= 128) ? sl.index * ((pll_wgs + c->pll_stagger - 1u) / c->pll_stagger * c->pll_stagger) : 0u;
+        const unsigned wg_skip = (c->pll_stagger && pll_wgs <= 128) ? (sl.index * ((pll_wgs + c->pll_stagger - 1u) / c->pll_stagger * c->pll_stagger)) % (unsigned)c->n_cus : 0u;
         for (auto &g : groups)
             HIP_OK(fx_launch_paypll(std::get<0>(g), (unsigned)std::get<2>(g), wg_skip, c->pll_waves, sl.stream_p, d_pjobs, d_pll_idx + std::get<1>(g),
                                     sl.d_symraw.p, sl.d_framesyms.p, sl.d_hard.p, sl.d_pres.p, c->d_tables));
