@@ -6,13 +6,13 @@
   config 5 (one GPU's share): 128 streams x 2^20 samples, modulation in {PSK4,QAM16,QAM32,QAM64} x inner 0..6 cycling
 
 Streams are synthesised on the host (16 distinct ones per config, tiled to the stream count), uploaded once, then
-every pass = reset + process of all streams.  Every injected frame is checked before a rate is printed."""
+every pass = reset + process of all streams, first one pass at a time, then with four passes in flight.  Every injected frame is checked before a rate is printed."""
 import argparse, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "3")
+os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "4")
 
 
 def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
@@ -46,9 +46,25 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
         ctx.reset(); ctx.process_raw(ptrs, counts, True)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / passes
     tm = ctx.timing()
+    # the same passes with several in flight (each pass is an independent capture of all streams: reset in between)
+    depth = 4
+    ctx.set_depth(depth)
+    def pipelined(k):
+        infl = 0
+        for _ in range(k):
+            if infl == depth:
+                ctx.collect_raw(); infl -= 1
+            ctx.reset(); ctx.submit_raw(ptrs, counts, True); infl += 1
+        while infl:
+            ctx.collect_raw(); infl -= 1
+    pipelined(depth)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    pipelined(3 * passes)
+    torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / (3 * passes)
     out = dict(config=name, streams=n_streams, samples_per_stream=n_samples, frames=len(res), checked_streams=min(n_streams, distinct),
                injected=n_inj, found=n_found, payload_ok=n_bytes_ok, all_frames_ok=bool(ok),
                ms_per_pass=round(dt * 1e3, 3), msamples_per_s=round(n_streams * n_samples / dt / 1e6, 1),
+               ms_per_pass_4_in_flight=round(dtp * 1e3, 3), msamples_per_s_4_in_flight=round(n_streams * n_samples / dtp / 1e6, 1),
                kernels_ms={k: round(tm[k], 3) for k in ("walk_ms", "paymf_ms", "paypll_ms", "paydec_ms")},
                hops=tm["hops"], hops_cheap=tm["hops_cheap"], walk_jobs=tm["walk_jobs"], repairs=tm["repairs"])
     print(json.dumps(out), flush=True)
