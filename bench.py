@@ -26,9 +26,9 @@ sys.path.insert(0, ROOT)
 
 # Runtime knobs, set before anything initialises HIP.  The pipeline keeps several blocks in flight on separate HIP
 # streams; HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them torch's), and
-# streams that share a queue serialise.  Sixteen queues let the two walk streams and ten payload streams (one per block in flight) run concurrently.
+# streams that share a queue serialise.  Sixteen queues let the two walk streams and the payload streams (the library creates one per block in flight) run
+# concurrently.  (libfxrx sets the same default itself when it is loaded before HIP initialises; torch gets there first here.)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
-os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "10")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy rate
 N_SAMPLES = 20_000_000         # 10 Msym at k = 2 samples/symbol

@@ -125,7 +125,9 @@ struct fxrx_ctx_s {
     // alternately by consecutive blocks, each running its block's PLL -> decode -> result copies in order.
     hipStream_t stream = nullptr;        // W: input staging, walker, payload MF, tail carry
     hipStream_t stream_p[16] = {};       // payload stage (MF -> PLL -> decode -> result copies), tied to the slots
-    unsigned n_pstreams = 2;
+    unsigned n_pstreams = 0;             // created so far
+    bool pstreams_fixed = false;         // FXRX_PAYLOAD_STREAMS given: do not grow with the pipeline depth
+    bool psplit = false; std::vector<uint32_t> pmask;   // CU mask of the payload streams (FXRX_PAYLOAD_SPLIT / FXRX_RESERVE_CUS)
     unsigned pll_waves = 1, dec_waves = 1;   // waves per workgroup of the PLL / decode grids (placement only)
     unsigned pll_stagger = 32;               // blocks in flight start their PLL grids this many workgroup slots apart (0 = off)
     int n_cus = 256;
@@ -216,12 +218,27 @@ int launch_walk(fxrx_ctx_s *c, Slot &sl, size_t first, size_t count)
 
 }  // namespace
 
+// HIP multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless told otherwise) and streams sharing a queue
+// serialise; the pipeline wants one queue per stream (2 walk + one payload stream per block in flight).  The runtime
+// reads the variable when it initialises, so this only helps when the library is loaded before the first HIP call.
+__attribute__((constructor)) static void fxrx_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 // ============================================================================ batched API
 extern "C" {
 
 const char *fxrx_last_error(void) { return g_err.c_str(); }
 const char *fxrx_version(void) { return "fxrx 0.1 (gfx950)"; }
 int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+
+static int ensure_pstreams(fxrx_ctx_s *c, unsigned want)
+{
+    for (; c->n_pstreams < std::min(want, 16u); c->n_pstreams++) {
+        hipStream_t *st = &c->stream_p[c->n_pstreams];
+        HIP_OK(c->psplit ? hipExtStreamCreateWithCUMask(st, (uint32_t)c->pmask.size(), c->pmask.data())
+                         : hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+    }
+    return 0;
+}
 
 static int make_slot(fxrx_ctx_s *c)
 {
@@ -246,7 +263,8 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     std::unique_ptr<fxrx_ctx_s> c(new fxrx_ctx_s);
     c->cfg = *cfg;
     if (c->cfg.threshold <= 0.0f) c->cfg.threshold = cfg->mode == FXRX_MODE_DETECTOR ? 0.45f : 0.5f;
-    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) c->n_pstreams = (unsigned)std::min(16, std::max(1, std::atoi(e)));
+    unsigned want_pstreams = 1;          // one per block in flight (fxrx_set_depth adds more) unless the environment says otherwise
+    if (const char *e = std::getenv("FXRX_PAYLOAD_STREAMS")) { want_pstreams = (unsigned)std::min(16, std::max(1, std::atoi(e))); c->pstreams_fixed = true; }
     if (const char *e = std::getenv("FXRX_PLL_WAVES")) c->pll_waves = (unsigned)std::min(4, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_PLL_STAGGER")) c->pll_stagger = (unsigned)std::min(256, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_DEC_WAVES")) c->dec_waves = (unsigned)std::min(8, std::max(1, std::atoi(e)));
@@ -283,13 +301,9 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
         int first = c->n_cus;
         // FXRX_RESERVE_CUS=<r>: payload streams stay off the first r CUs, which the (unmasked) walker then always finds empty
         if (const char *r = std::getenv("FXRX_RESERVE_CUS")) { const int v = std::atoi(r); if (v > 0 && v < ncu) { split = true; first = v; } }
-        std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0u);
-        for (int i = first; i < ncu; i++) mask[(size_t)i / 32] |= 1u << (i % 32);
-        for (unsigned i = 0; i < c->n_pstreams; i++) {
-            const hipError_t err = split ? hipExtStreamCreateWithCUMask(&c->stream_p[i], (uint32_t)mask.size(), mask.data())
-                                         : hipStreamCreateWithFlags(&c->stream_p[i], hipStreamNonBlocking);
-            if (err != hipSuccess) { set_err("hipStreamCreate failed"); return nullptr; }
-        }
+        c->psplit = split; c->pmask.assign((size_t)(ncu + 31) / 32, 0u);
+        for (int i = first; i < ncu; i++) c->pmask[(size_t)i / 32] |= 1u << (i % 32);
+        if (ensure_pstreams(c.get(), want_pstreams) != 0) return nullptr;
     }
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_EARLY_WALK")) c->early_walk = std::atoi(e) != 0;
@@ -336,7 +350,9 @@ int fxrx_set_depth(fxrx_ctx *c, unsigned int depth)
     if (!c || depth == 0 || depth > 16) return FXRX_ERR_ARG;
     if (c->inflight) { set_err("fxrx_set_depth: blocks in flight"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
+    if (!c->pstreams_fixed && ensure_pstreams(c, depth) != 0) return FXRX_ERR_HIP;     // one payload stream per block in flight
     while (c->slots.size() < depth) if (make_slot(c) != 0) return FXRX_ERR_HIP;
+    for (auto &sl : c->slots) sl->stream_p = sl->stream_d = c->stream_p[sl->index % c->n_pstreams];
     c->depth = depth; c->head = c->tail = 0;
     return 0;
 }

@@ -11,8 +11,7 @@ import argparse, importlib, json, os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
-os.environ.setdefault("FXRX_PAYLOAD_STREAMS", "4")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
