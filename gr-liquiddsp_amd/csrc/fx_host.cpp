@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <chrono>
+#include <deque>
 #include <cstdio>
 #include <cstdlib>
 #include <memory>
@@ -89,6 +90,11 @@ struct PlanDev { fx::PacketPlan plan; uint32_t perm0_off, perm1_off; };
 
 struct Out { fxrx_frame f; int pjob; };
 
+// One stream's stitched result for a block.  A chain also lists its seek spans: runs of hops [pos, end) on which the
+// walkers reported no detection; with hop skipping enabled these are what fx_seekverify_kernel re-checks.
+struct Span { int64_t pos, floor_, end; };
+struct Chain { std::vector<FxFrame> frames; std::vector<Span> spans; int64_t pos = 0, floor_ = 0; bool fresh = true; };
+
 // One in-flight block's payload stage: its own arenas, staging and result buffers, so that the PLL of
 // block n, the packet decode of block n-1 and the walk of block n+1 can run concurrently on three streams.
 struct Slot {
@@ -115,7 +121,11 @@ struct Slot {
     std::vector<const float2 *> xs; std::vector<int64_t> ns; std::vector<size_t> first_job;
     size_t NJ = 0; uint32_t repair_base = 0, repair_cap = 256;
     uint64_t epoch = 0;                  // fxrx_reset generation the block was submitted in
-    bool walking = false;                // walk launched, completion phase (stitch .. payload launch) still to run
+    // a block's way through the host: walk_phase -> (WALKING) -> stitch_phase -> (VERIFYING) -> finish_phase -> (LAUNCHED)
+    enum { IDLE = 0, WALKING = 1, VERIFYING = 2, LAUNCHED = 3 };
+    int stage = IDLE;
+    std::vector<Chain> chains;           // stitched per stream (stitch_phase), consumed by finish_phase
+    std::vector<unsigned> vj_stream;     // stream of every verification run launched by stitch_phase
 };
 
 struct fxrx_ctx_s {
@@ -134,7 +144,7 @@ struct fxrx_ctx_s {
     hipStream_t stream2 = nullptr;       // second walk stream: consecutive independent blocks alternate (see fxrx_submit)
     bool early_walk = true;              // FXRX_EARLY_WALK=0: never launch a walk before the previous block is stitched
     uint64_t epoch = 0;     // fxrx_reset generation; blocks submitted so far
-    struct Slot *pending = nullptr;      // the block whose walk is launched but not yet stitched (at most one)
+    std::deque<struct Slot *> pending;   // blocks whose payload stage is not launched yet, oldest first
     hipEvent_t ev_last_mf = nullptr;     // end of the most recent payload MF (borrowed from its slot): guards the work buffers
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
@@ -448,35 +458,19 @@ static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint
     if (launch_walk(c, sl, 0, NJ)) return FXRX_ERR_HIP;
     HIP_OK(hipEventRecord(sl.ev_w1, sl.stream_w));
     sl.timing.walk_jobs = NJ;
-    sl.walking = true;
+    sl.stage = Slot::WALKING;
     sl.timing.host_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     return 0;
 }
 
 // ---- phase 2: wait for the walkers, stitch, verify the skipped hops, launch the payload stage, carry the tails ----
-static int complete_phase(fxrx_ctx_s *c, Slot &sl)
+// ---- stitch one stream: splice the speculative lists into the sequential chain ----
+static int stitch_stream(fxrx_ctx_s *c, Slot &sl, unsigned s)
 {
-    const unsigned NS = c->cfg.n_streams;
-    const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
-    const auto t_enter = std::chrono::steady_clock::now();
-    std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns; std::vector<size_t> &first_job = sl.first_job;
+    const std::vector<size_t> &first_job = sl.first_job;
     const size_t NJ = sl.NJ; const uint32_t repair_base = sl.repair_base, repair_cap = sl.repair_cap;
-    for (auto &w : c->walk_stamp) w = 0;
-    c->walk_stamp_max = 0;
     {
-        const auto tw = std::chrono::steady_clock::now();
-        HIP_OK(hipStreamSynchronize(sl.stream_w));
-        sl.timing.host_walkwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
-    }
-
-    // ---- 3. stitch: per stream, splice speculative lists into the sequential chain ----
-    // A chain also lists its seek spans: runs of hops [pos, end) on which the walkers reported no detection.  With
-    // hop skipping enabled these are what fx_seekverify_kernel re-checks with the full detector (step 3b).
-    struct Span { int64_t pos, floor_, end; };
-    struct Chain { std::vector<FxFrame> frames; std::vector<Span> spans; int64_t pos, floor_; bool fresh; };
-    std::vector<Chain> chains(NS);
-    auto stitch_stream = [&](unsigned s) -> int {
-        Chain &ch = chains[s];
+        Chain &ch = sl.chains[s];
         ch.frames.clear(); ch.spans.clear();
         auto add_span = [&](int64_t p, int64_t fl, int64_t e) { if (e > p) ch.spans.push_back(Span{ p, fl, e }); };
         size_t cur = first_job[s]; uint32_t m = 0;
@@ -542,18 +536,38 @@ static int complete_phase(fxrx_ctx_s *c, Slot &sl)
             cur = nxt;
         }
         return 0;
-    };
-    for (unsigned s = 0; s < NS; s++) if (stitch_stream(s)) return FXRX_ERR_HIP;
+    }
+}
+
+// ---- phase 2: wait for the walkers, stitch every stream's chain, launch the seek verification ----
+static int stitch_phase(fxrx_ctx_s *c, Slot &sl)
+{
+    const unsigned NS = c->cfg.n_streams;
+    const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
+    const auto t_enter = std::chrono::steady_clock::now();
+    std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns;
+    for (auto &w : c->walk_stamp) w = 0;
+    c->walk_stamp_max = 0;
+    {
+        // (events, not the stream: the walk of the block after next may already be queued behind this one's)
+        const auto tw = std::chrono::steady_clock::now();
+        HIP_OK(hipEventSynchronize(sl.ev_w1));
+        sl.timing.host_walkwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+    }
+    sl.chains.assign(NS, Chain{});
+    for (unsigned s = 0; s < NS; s++) if (stitch_stream(c, sl, s)) return FXRX_ERR_HIP;
     float ms = 0;
     (void)hipEventElapsedTime(&ms, sl.ev_w0, sl.ev_w1); sl.timing.walk_ms = ms;
 
-    // ---- 3b. seek verification: the full detector over every hop the chains' walkers skipped ----
+    // seek verification: the full detector over every hop the chains' walkers skipped
+    sl.vj_stream.clear();
     if (!detect && c->skip_seek) {
+        const std::vector<Chain> &chains = sl.chains;
         uint64_t tot_hops = 0;
         for (unsigned s = 0; s < NS; s++) for (const Span &sp : chains[s].spans) tot_hops += (uint64_t)(sp.end - sp.pos) / FX_HOP;
         // runs of at most `per` hops: about four workgroups per CU, so that the grid drains evenly
         const uint64_t per = std::min<uint64_t>(16, std::max<uint64_t>(1, (tot_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
-        std::vector<FxVerifyJob> vj; std::vector<unsigned> vj_stream;
+        std::vector<FxVerifyJob> vj;
         for (unsigned s = 0; s < NS; s++)
             for (const Span &sp : chains[s].spans) {
                 const uint64_t nh = (uint64_t)(sp.end - sp.pos) / FX_HOP;
@@ -561,7 +575,7 @@ static int complete_phase(fxrx_ctx_s *c, Slot &sl)
                     FxVerifyJob j{};
                     j.x = xs[s]; j.n = ns[s]; j.pos = sp.pos + (int64_t)(h * FX_HOP); j.floor = sp.floor_;
                     j.nhops = (uint32_t)std::min<uint64_t>(per, nh - h); j.threshold = c->cfg.threshold;
-                    vj.push_back(j); vj_stream.push_back(s);
+                    vj.push_back(j); sl.vj_stream.push_back(s);
                 }
             }
         sl.timing.verify_hops = tot_hops;
@@ -571,28 +585,44 @@ static int complete_phase(fxrx_ctx_s *c, Slot &sl)
             HIP_OK(hipEventRecord(sl.ev_v0, sl.stream_w));
             HIP_OK(fx_launch_seekverify((unsigned)vj.size(), sl.stream_w, sl.hp_vjobs.p, sl.h_vres.p, c->d_tables));
             HIP_OK(hipEventRecord(sl.ev_v1, sl.stream_w));
-            {
-                const auto tw = std::chrono::steady_clock::now();
-                HIP_OK(hipStreamSynchronize(sl.stream_w));
-                sl.timing.host_walkwait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        }
+    }
+    sl.stage = Slot::VERIFYING;
+    sl.timing.host_submit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    return 0;
+}
+
+// ---- phase 3: check the verification, launch the payload stage, carry the tails ----
+static int finish_phase(fxrx_ctx_s *c, Slot &sl)
+{
+    const unsigned NS = c->cfg.n_streams;
+    const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
+    const auto t_enter = std::chrono::steady_clock::now();
+    std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns; std::vector<size_t> &first_job = sl.first_job;
+    std::vector<Chain> &chains = sl.chains;
+    float ms = 0;
+    if (!sl.vj_stream.empty()) {
+        {
+            const auto tw = std::chrono::steady_clock::now();
+            HIP_OK(hipEventSynchronize(sl.ev_v1));
+            sl.timing.host_walkwait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
+        }
+        (void)hipEventElapsedTime(&ms, sl.ev_v0, sl.ev_v1); sl.timing.seekverify_ms = ms;
+        // A skipped hop on which the detector does fire (a false alarm, or a preamble too weak for the coarse
+        // scan): that stream's chain is void from there on.  Walk the stream again with skipping off -- exact
+        // by itself, as in the first version of this walker -- and stitch it again.
+        std::vector<char> bad(NS, 0); unsigned n_bad = 0;
+        for (size_t i = 0; i < sl.vj_stream.size(); i++)
+            if (sl.h_vres.p[i].det_hop != 0xFFFFFFFFu && !bad[sl.vj_stream[i]]) { bad[sl.vj_stream[i]] = 1; n_bad++; }
+        if (n_bad) {
+            sl.timing.verify_failures = n_bad;
+            for (unsigned s = 0; s < NS; s++) {
+                if (!bad[s]) continue;
+                for (size_t j = first_job[s]; j < first_job[s + 1]; j++) sl.jobs[j].no_skip = 1u;
+                if (launch_walk(c, sl, first_job[s], first_job[s + 1] - first_job[s])) return FXRX_ERR_HIP;
             }
-            (void)hipEventElapsedTime(&ms, sl.ev_v0, sl.ev_v1); sl.timing.seekverify_ms = ms;
-            // A skipped hop on which the detector does fire (a false alarm, or a preamble too weak for the coarse
-            // scan): that stream's chain is void from there on.  Walk the stream again with skipping off -- exact
-            // by itself, as in the first version of this walker -- and stitch it again.
-            std::vector<char> bad(NS, 0); unsigned n_bad = 0;
-            for (size_t i = 0; i < vj.size(); i++)
-                if (sl.h_vres.p[i].det_hop != 0xFFFFFFFFu && !bad[vj_stream[i]]) { bad[vj_stream[i]] = 1; n_bad++; }
-            if (n_bad) {
-                sl.timing.verify_failures = n_bad;
-                for (unsigned s = 0; s < NS; s++) {
-                    if (!bad[s]) continue;
-                    for (size_t j = first_job[s]; j < first_job[s + 1]; j++) sl.jobs[j].no_skip = 1u;
-                    if (launch_walk(c, sl, first_job[s], first_job[s + 1] - first_job[s])) return FXRX_ERR_HIP;
-                }
-                HIP_OK(hipStreamSynchronize(sl.stream_w));
-                for (unsigned s = 0; s < NS; s++) if (bad[s] && stitch_stream(s)) return FXRX_ERR_HIP;
-            }
+            HIP_OK(hipStreamSynchronize(sl.stream_w));
+            for (unsigned s = 0; s < NS; s++) if (bad[s] && stitch_stream(c, sl, s)) return FXRX_ERR_HIP;
         }
     }
 
@@ -724,27 +754,41 @@ static int complete_phase(fxrx_ctx_s *c, Slot &sl)
         S.pos = ch.pos - keep_from; S.floor_ = ch.floor_ - keep_from; S.fresh = ch.fresh;
     }
     HIP_OK(hipEventRecord(sl.ev_carry, sl.stream_w));
-    sl.walking = false;
+    sl.stage = Slot::LAUNCHED;
     sl.timing.host_submit_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
     return 0;
 }
 
-// A block goes through walk_phase, then complete_phase.  The completion of block k needs the host (it stitches), and
-// the walk of block k+1 needs the stream state block k leaves behind -- unless the streams were reset in between
-// (independent captures, the bench's passes): then walk k+1 is launched first, on the other walk stream, and runs
-// while the host stitches / verifies / launches block k.  A continuing stream completes k before it walks k+1.
+// A block goes through walk_phase, stitch_phase, finish_phase.  The last two need the host, and the walk of block k+1
+// needs the stream state block k leaves behind -- unless the streams were reset in between (independent captures, the
+// bench's passes).  Then the host never has to wait: a submit launches the new block's walk, finishes the block
+// whose verification was launched by the previous submit, and stitches the block whose walk was launched by the
+// previous submit (launching its verification).  A continuing stream runs all three phases of block k before it
+// walks block k+1.
+static int advance_front(fxrx_ctx_s *c)          // one phase of the oldest pending block
+{
+    Slot *p = c->pending.front();
+    if (p->stage == Slot::WALKING) return stitch_phase(c, *p);
+    if (finish_phase(c, *p)) return FXRX_ERR_HIP;
+    c->pending.pop_front();
+    return 0;
+}
+
 int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device)
 {
     if (!c || !iq || !n_samples) { set_err("fxrx_submit: null argument"); return FXRX_ERR_ARG; }
     if (c->inflight >= c->depth) { set_err("fxrx_submit: pipeline full, call fxrx_collect first"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
     Slot &sl = *c->slots[c->head];
-    bool early = c->early_walk && c->pending != nullptr && on_device && c->pending->epoch != c->epoch;
+    bool early = c->early_walk && !c->pending.empty() && on_device && c->pending.back()->epoch != c->epoch;
     for (const auto &S : c->st) if (S.carry_len != 0 || !S.fresh) early = false;
-    if (c->pending && !early) { Slot *p = c->pending; c->pending = nullptr; if (complete_phase(c, *p)) return FXRX_ERR_HIP; }
+    if (!early) while (!c->pending.empty()) if (advance_front(c)) return FXRX_ERR_HIP;
     if (walk_phase(c, sl, iq, n_samples, on_device)) return FXRX_ERR_HIP;
-    if (c->pending) { Slot *p = c->pending; c->pending = nullptr; if (complete_phase(c, *p)) return FXRX_ERR_HIP; }
-    c->pending = &sl;
+    // software pipeline over the blocks already pending: finish the one that is being verified, stitch the next
+    if (!c->pending.empty() && c->pending.front()->stage == Slot::VERIFYING) if (advance_front(c)) return FXRX_ERR_HIP;
+    for (Slot *p : c->pending) if (p->stage == Slot::WALKING) { if (stitch_phase(c, *p)) return FXRX_ERR_HIP; break; }
+    while (c->pending.size() >= 2) if (advance_front(c)) return FXRX_ERR_HIP;     // (never more than one block behind the one being verified)
+    c->pending.push_back(&sl);
     sl.busy = true;
     c->head = (c->head + 1) % c->depth; c->inflight++;
     return 0;
@@ -756,10 +800,7 @@ int fxrx_collect(fxrx_ctx *c)
     if (!c->inflight) { set_err("fxrx_collect: nothing in flight"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
     Slot &sl = *c->slots[c->tail];
-    if (sl.walking) {                                // the newest block: nobody has stitched it yet
-        if (c->pending == &sl) c->pending = nullptr;
-        if (complete_phase(c, sl)) return FXRX_ERR_HIP;
-    }
+    while (sl.stage != Slot::LAUNCHED) if (advance_front(c)) return FXRX_ERR_HIP;     // blocks are pending in order: the oldest is this one
     {
         const auto tw = std::chrono::steady_clock::now();
         HIP_OK(hipEventSynchronize(sl.ev_done));
