@@ -76,11 +76,17 @@ template <class T> struct PinBuf {
 };
 
 struct StreamState {
-    DevBuf<float2> carry[2]; int cur = 0;   // double-buffered tail of the previous call
+    DevBuf<float2> carry[2]; int cur = 0;   // double-buffered tail of the previous block
     size_t carry_len = 0;
-    int64_t base = 0;                       // absolute index of work-buffer sample 0
-    int64_t pos = 0, floor_ = 0; bool fresh = true;   // resume state, relative to the work buffer
-    DevBuf<float2> work;                    // [carry | new] when a tail exists or input is on the host
+    int64_t total = 0;                      // absolute index of the next new sample (since the last reset)
+    int64_t pos = 0, floor_ = 0; bool fresh = true;   // resume state, relative to carry sample 0
+    // [headroom | carry | new] staging when a tail exists, input is on the host, or the block is walked speculatively.
+    // Two buffers, used alternately: the payload MF of block k may still be reading one while block k+1 is staged.
+    DevBuf<float2> work[2]; int wcur = 0;
+    hipEvent_t work_mf[2] = { nullptr, nullptr };   // end of the last MF that read work[i] (borrowed from its slot)
+    hipEvent_t work_rd[2] = { nullptr, nullptr };   // end of the last tail copy that read work[i] (likewise)
+    hipEvent_t carry_ev = nullptr;                  // end of the copy that filled carry[cur] (borrowed from its slot)
+    size_t max_keep = 0;                            // longest tail carried so far (sizes the speculative headroom)
 };
 
 struct PlanKey { unsigned n, check, fec0, fec1; bool operator<(const PlanKey &o) const { return std::tie(n, check, fec0, fec1) < std::tie(o.n, o.check, o.fec0, o.fec1); } };
@@ -125,6 +131,13 @@ struct Slot {
     enum { IDLE = 0, WALKING = 1, VERIFYING = 2, LAUNCHED = 3 };
     int stage = IDLE;
     std::vector<Chain> chains;           // stitched per stream (stitch_phase), consumed by finish_phase
+    std::vector<int64_t> base;           // absolute sample index of coordinate 0 of xs[s]
+    std::vector<int> wbuf;               // which of the stream's work buffers xs[s] is (-1: the caller's buffer)
+    // speculative block of a continuing stream (see fxrx_submit): the true walker of every stream (its job 0) is
+    // launched by stitch_phase, once the previous block has left its resume state and tail behind
+    bool late0 = false; int64_t headroom = 0;
+    std::vector<int64_t> tot0;           // absolute index of the block's first new sample, per stream
+    std::vector<const void *> in_ptr; std::vector<uint64_t> in_n; int in_dev = 0;   // the input, for a re-stage
     std::vector<unsigned> vj_stream;     // stream of every verification run launched by stitch_phase
 };
 
@@ -145,7 +158,6 @@ struct fxrx_ctx_s {
     bool early_walk = true;              // FXRX_EARLY_WALK=0: never launch a walk before the previous block is stitched
     uint64_t epoch = 0;     // fxrx_reset generation; blocks submitted so far
     std::deque<struct Slot *> pending;   // blocks whose payload stage is not launched yet, oldest first
-    hipEvent_t ev_last_mf = nullptr;     // end of the most recent payload MF (borrowed from its slot): guards the work buffers
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
     bool skip_seek = true;               // FXRX_SKIP_SEEK=0: walkers run the full detector on every hop (no verification pass)
@@ -352,7 +364,8 @@ void fxrx_reset(fxrx_ctx *c)
 {
     if (!c) return;
     c->epoch++;
-    for (auto &s : c->st) { s.carry_len = 0; s.base = 0; s.pos = 0; s.floor_ = 0; s.fresh = true; }
+    for (auto &s : c->st) { s.carry_len = 0; s.total = 0; s.pos = 0; s.floor_ = 0; s.fresh = true; s.carry_ev = nullptr; }
+    // (work-buffer guards stay: blocks in flight may still be reading them)
 }
 
 int fxrx_set_depth(fxrx_ctx *c, unsigned int depth)
@@ -379,39 +392,71 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
 }
 
 // ---- phase 1 of a block: stage its input, cut it into segments, launch the walkers (nothing is waited for) ----
-static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint64_t *n_samples, int on_device)
+enum { WALK_SERIAL = 0, WALK_SPEC = 1, WALK_RESTAGE = 2 };
+
+// mode WALK_SERIAL: the streams' resume state is known (nothing pending, or the streams were reset): job 0 of every
+//   stream is the true walker, everything is launched at once.
+// mode WALK_SPEC: a continuing stream whose previous block is still pending.  The new samples are staged behind a
+//   headroom that will take the tail once it is known, the speculative walkers of all segments are launched at once,
+//   and job 0 is a placeholder that stitch_phase replaces by the true walker (a short walk up to its hand-off).
+// mode WALK_RESTAGE: a WALK_SPEC block whose tail turned out longer than the headroom: staged and walked again, serially.
+static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint64_t *n_samples, int on_device, int mode)
 {
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
-    sl.out.clear(); sl.timing = fxrx_timing{};
     const auto t_enter = std::chrono::steady_clock::now();
-    // Streams are tied to slots, not to blocks: the HIP runtime tracks which queue last touched a buffer that takes part
-    // in a hipMemcpyAsync and makes the next queue wait for the previous one, so handing a slot's arenas to a different
-    // stream every time serialises the payload stages (measured: 10.7 instead of 17.8 Gsamples/s).
-    sl.stream_w = (sl.index & 1u) ? c->stream2 : c->stream;
-    sl.epoch = c->epoch;
+    if (mode != WALK_RESTAGE) {
+        sl.out.clear(); sl.timing = fxrx_timing{};
+        // Streams are tied to slots, not to blocks: the HIP runtime tracks which queue last touched a buffer that takes part
+        // in a hipMemcpyAsync and makes the next queue wait for the previous one, so handing a slot's arenas to a different
+        // stream every time serialises the payload stages (measured: 10.7 instead of 17.8 Gsamples/s).
+        sl.stream_w = (sl.index & 1u) ? c->stream2 : c->stream;
+        sl.epoch = c->epoch;
+        sl.in_ptr.assign(iq, iq + NS); sl.in_n.assign(n_samples, n_samples + NS); sl.in_dev = on_device;
+    }
+    const bool spec = mode == WALK_SPEC;
+    sl.late0 = spec;
     std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns; std::vector<size_t> &first_job = sl.first_job;
-    xs.assign(NS, nullptr); ns.assign(NS, 0); first_job.assign(NS + 1, 0);
+    const std::vector<int> wbuf_prev = sl.wbuf;
+    xs.assign(NS, nullptr); ns.assign(NS, 0); first_job.assign(NS + 1, 0); sl.base.assign(NS, 0); sl.wbuf.assign(NS, -1);
+    if (mode != WALK_RESTAGE) sl.tot0.assign(NS, 0);
 
-    // ---- 1. per-stream work buffers: [tail of previous call | new samples] ----
+    // ---- 1. per-stream work buffers: [headroom | tail of the previous block | new samples] ----
     uint64_t total_new = 0;
+    int64_t H = 0;
+    if (spec) {
+        size_t mk = 0; for (const auto &S : c->st) mk = std::max(mk, std::max(S.max_keep, S.carry_len));
+        H = (int64_t)std::max<size_t>(131072, 2 * mk + 4096);
+    }
+    sl.headroom = H;
     for (unsigned s = 0; s < NS; s++) {
         StreamState &S = c->st[s];
         const uint64_t nn = n_samples[s];
         total_new += nn;
-        if (S.carry_len == 0 && on_device) { xs[s] = (const float2 *)iq[s]; ns[s] = (int64_t)nn; continue; }
-        if (c->ev_last_mf) { HIP_OK(hipStreamWaitEvent(sl.stream_w, c->ev_last_mf, 0)); c->ev_last_mf = nullptr; }   // that MF reads S.work
-        if (S.work.reserve(S.carry_len + nn + 1)) return FXRX_ERR_HIP;
-        if (S.carry_len) HIP_OK(hipMemcpyAsync(S.work.p, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
-        if (nn) HIP_OK(hipMemcpyAsync(S.work.p + S.carry_len, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sl.stream_w));
-        xs[s] = S.work.p; ns[s] = (int64_t)(S.carry_len + nn);
+        if (mode != WALK_RESTAGE) { sl.tot0[s] = S.total; S.total += (int64_t)nn; }
+        const int64_t total_before = sl.tot0[s];
+        if (!spec && S.carry_len == 0 && on_device) { xs[s] = (const float2 *)iq[s]; ns[s] = (int64_t)nn; sl.base[s] = total_before; continue; }
+        const int b = (mode == WALK_RESTAGE && s < wbuf_prev.size() && wbuf_prev[s] >= 0) ? wbuf_prev[s] : (S.wcur ^= 1);
+        DevBuf<float2> &W = S.work[b];
+        // the payload MF and the tail copy of the block that used this buffer last may still be reading it (other streams)
+        if (S.work_mf[b]) { HIP_OK(hipStreamWaitEvent(sl.stream_w, S.work_mf[b], 0)); S.work_mf[b] = nullptr; }
+        if (S.work_rd[b]) { HIP_OK(hipStreamWaitEvent(sl.stream_w, S.work_rd[b], 0)); S.work_rd[b] = nullptr; }
+        const size_t lead = spec ? (size_t)H : S.carry_len;
+        if (W.reserve(lead + nn + 1)) return FXRX_ERR_HIP;
+        if (!spec && S.carry_len) {
+            if (S.carry_ev) HIP_OK(hipStreamWaitEvent(sl.stream_w, S.carry_ev, 0));
+            HIP_OK(hipMemcpyAsync(W.p, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
+        }
+        if (nn) HIP_OK(hipMemcpyAsync(W.p + lead, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sl.stream_w));
+        xs[s] = W.p; ns[s] = (int64_t)(lead + nn); sl.base[s] = total_before - (int64_t)lead; sl.wbuf[s] = b;
     }
     sl.timing.samples = total_new;
 
     // ---- 2. walk jobs: cut every stream into segments ----
     uint64_t seg = c->cfg.segment_len;
     if (seg == 0) {
-        uint64_t tot = 0; for (unsigned s = 0; s < NS; s++) tot += (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
+        uint64_t tot = 0;
+        for (unsigned s = 0; s < NS; s++) tot += spec ? n_samples[s] : (uint64_t)std::max<int64_t>(0, ns[s] - c->st[s].pos);
         // Walker workgroups resident at once: two per CU for the flex_rx instance (4 waves x 256 VGPRs each), two for the
         // leaner detector-only instance.  Little work: a single round of workgroups with a small margin (the kernel
         // then lasts as long as its slowest segment).  Lots of work: ~4 rounds so that uneven segments even out.
@@ -426,22 +471,25 @@ static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint
     for (unsigned s = 0; s < NS; s++) {
         StreamState &S = c->st[s];
         first_job[s] = sl.jobs.size();
-        int64_t p = S.pos;
+        // speculative block: the true walker only has to reach its first hand-off, so its own segment is short
+        int64_t p = spec ? H : S.pos;
+        const int64_t seg0 = spec ? (int64_t)std::min<uint64_t>(seg, 8192) : (int64_t)seg;
         bool first = true;
         while (first || p < ns[s]) {
             FxWalkJob j{};
             j.x = xs[s]; j.n = ns[s]; j.start = p;
-            j.stop = std::min<int64_t>(ns[s], p + (int64_t)seg);
+            j.stop = std::min<int64_t>(ns[s], p + (first ? seg0 : (int64_t)seg));
             if (ns[s] - j.stop < (int64_t)seg / 2) j.stop = ns[s];          // fold a short last segment in
             j.fresh = first ? (S.fresh ? 1u : 0u) : 1u;
             j.floor = first ? S.floor_ : p;
             j.mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
             j.handoff = j.stop < ns[s] ? 1u : 0u;
             j.prelock = first ? 0u : 1u;
-            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start));
+            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && spec ? 65536u : 0u));
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
             j.no_skip = (detect || !c->skip_seek) ? 1u : 0u;
+            if (first && spec) { j.start = j.stop; j.fresh = 1u; j.floor = j.stop; j.handoff = 0u; }   // placeholder: exits at once
             sl.jobs.push_back(j); sl.job_stream.push_back(s);
             p = j.stop; first = false;
             if (p >= ns[s]) break;
@@ -459,11 +507,11 @@ static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint
     HIP_OK(hipEventRecord(sl.ev_w1, sl.stream_w));
     sl.timing.walk_jobs = NJ;
     sl.stage = Slot::WALKING;
-    sl.timing.host_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    const double dt = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_enter).count();
+    if (mode == WALK_RESTAGE) sl.timing.host_submit_ms += dt; else sl.timing.host_submit_ms = dt;
     return 0;
 }
 
-// ---- phase 2: wait for the walkers, stitch, verify the skipped hops, launch the payload stage, carry the tails ----
 // ---- stitch one stream: splice the speculative lists into the sequential chain ----
 static int stitch_stream(fxrx_ctx_s *c, Slot &sl, unsigned s)
 {
@@ -548,6 +596,31 @@ static int stitch_phase(fxrx_ctx_s *c, Slot &sl)
     std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns;
     for (auto &w : c->walk_stamp) w = 0;
     c->walk_stamp_max = 0;
+    if (sl.late0) {
+        // Speculative block of a continuing stream: the previous block is finished by now, so the tail and the resume
+        // state are known.  Put the tail in front of the new samples and launch every stream's true walker (job 0).
+        bool fits = true;
+        for (unsigned s = 0; s < NS; s++) if ((int64_t)c->st[s].carry_len > sl.headroom) fits = false;
+        if (!fits) {                                  // (rare) a tail longer than the headroom: stage and walk again, serially
+            HIP_OK(hipEventSynchronize(sl.ev_w1));
+            if (walk_phase(c, sl, sl.in_ptr.data(), sl.in_n.data(), sl.in_dev, WALK_RESTAGE)) return FXRX_ERR_HIP;
+        } else {
+            for (unsigned s = 0; s < NS; s++) {
+                StreamState &S = c->st[s];
+                const int64_t c0 = sl.headroom - (int64_t)S.carry_len;          // coordinate of tail sample 0
+                if (S.carry_len) {
+                    if (S.carry_ev) HIP_OK(hipStreamWaitEvent(sl.stream_w, S.carry_ev, 0));
+                    HIP_OK(hipMemcpyAsync(const_cast<float2 *>(xs[s]) + c0, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
+                }
+                FxWalkJob &j = sl.jobs[sl.first_job[s]];
+                j.start = c0 + S.pos; j.floor = c0 + S.floor_; j.fresh = S.fresh ? 1u : 0u;
+                j.handoff = j.stop < ns[s] ? 1u : 0u;
+                if (launch_walk(c, sl, sl.first_job[s], 1)) return FXRX_ERR_HIP;
+            }
+            HIP_OK(hipEventRecord(sl.ev_w1, sl.stream_w));
+            sl.late0 = false;
+        }
+    }
     {
         // (events, not the stream: the walk of the block after next may already be queued behind this one's)
         const auto tw = std::chrono::steady_clock::now();
@@ -633,7 +706,7 @@ static int finish_phase(fxrx_ctx_s *c, Slot &sl)
     for (unsigned s = 0; s < NS; s++) {
         for (const FxFrame &f : chains[s].frames) {
             Out o{}; std::memset(&o.f, 0, sizeof o.f);
-            o.f.stream = s; o.f.start = c->st[s].base + f.start; o.f.cfo_bin = f.offset;
+            o.f.stream = s; o.f.start = sl.base[s] + f.start; o.f.cfo_bin = f.offset;
             o.f.rxy = f.rxy; o.f.tau = f.tau; o.f.gamma = f.gamma; o.f.dphi = f.dphi; o.f.phi = f.phi; o.f.pfb_index = f.pfb;
             o.f.pilot_dphi = f.pilot_dphi; o.f.pilot_phi = f.pilot_phi; o.f.pilot_gain = f.pilot_gain;
             o.f.header_valid = (f.flags & FX_FLAG_HEADER_VALID) ? 1 : 0;
@@ -712,7 +785,7 @@ static int finish_phase(fxrx_ctx_s *c, Slot &sl)
                            d_pjobs, d_blk_job, d_blk_c0, sl.d_symraw.p, c->d_tables);
         HIP_OK(hipGetLastError());
         HIP_OK(hipEventRecord(sl.ev_mf1, sl.stream_p));
-        c->ev_last_mf = sl.ev_mf1;
+        for (unsigned s = 0; s < NS; s++) if (sl.wbuf[s] >= 0) c->st[s].work_mf[sl.wbuf[s]] = sl.ev_mf1;   // guards the work buffers
         // P: payload PLL
         HIP_OK(hipEventRecord(sl.ev_pll0, sl.stream_p));
         // stagger concurrent blocks' PLL grids over different CUs (see the kernel): slot k skips k * (grid rounded to 32)
@@ -750,7 +823,8 @@ static int finish_phase(fxrx_ctx_s *c, Slot &sl)
             if (S.carry[nxt].reserve(keep)) return FXRX_ERR_HIP;
             HIP_OK(hipMemcpyAsync(S.carry[nxt].p, xs[s] + keep_from, keep * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
         }
-        S.cur = nxt; S.carry_len = keep; S.base += keep_from;
+        S.cur = nxt; S.carry_len = keep; S.max_keep = std::max(S.max_keep, keep); S.carry_ev = sl.ev_carry;
+        if (sl.wbuf[s] >= 0) S.work_rd[sl.wbuf[s]] = sl.ev_carry;
         S.pos = ch.pos - keep_from; S.floor_ = ch.floor_ - keep_from; S.fresh = ch.fresh;
     }
     HIP_OK(hipEventRecord(sl.ev_carry, sl.stream_w));
@@ -780,13 +854,29 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     if (c->inflight >= c->depth) { set_err("fxrx_submit: pipeline full, call fxrx_collect first"); return FXRX_ERR_STATE; }
     HIP_OK(hipSetDevice(c->cfg.device));
     Slot &sl = *c->slots[c->head];
-    bool early = c->early_walk && !c->pending.empty() && on_device && c->pending.back()->epoch != c->epoch;
-    for (const auto &S : c->st) if (S.carry_len != 0 || !S.fresh) early = false;
-    if (!early) while (!c->pending.empty()) if (advance_front(c)) return FXRX_ERR_HIP;
-    if (walk_phase(c, sl, iq, n_samples, on_device)) return FXRX_ERR_HIP;
-    // software pipeline over the blocks already pending: finish the one that is being verified, stitch the next
-    if (!c->pending.empty() && c->pending.front()->stage == Slot::VERIFYING) if (advance_front(c)) return FXRX_ERR_HIP;
-    for (Slot *p : c->pending) if (p->stage == Slot::WALKING) { if (stitch_phase(c, *p)) return FXRX_ERR_HIP; break; }
+    const unsigned NS = c->cfg.n_streams;
+    // independent of everything pending: the streams were reset after the newest pending block was submitted
+    bool indep = c->early_walk && !c->pending.empty() && on_device && c->pending.back()->epoch != c->epoch;
+    for (const auto &S : c->st) if (S.carry_len != 0 || !S.fresh) indep = false;
+    // continuing the newest pending block, and big enough to be worth walking speculatively
+    bool cont = c->early_walk && !indep && !c->pending.empty() && c->pending.back()->epoch == c->epoch && NS <= 8;
+    for (unsigned s = 0; s < NS; s++) if (n_samples[s] < (1u << 18)) cont = false;
+    auto finish_front = [&]() -> int { return (!c->pending.empty() && c->pending.front()->stage == Slot::VERIFYING) ? advance_front(c) : 0; };
+    auto stitch_next = [&]() -> int {
+        for (Slot *p : c->pending) if (p->stage == Slot::WALKING) return stitch_phase(c, *p);
+        return 0;
+    };
+    if (indep) {                     // software pipeline: the new walk first, then one phase each of the two blocks behind it
+        if (walk_phase(c, sl, iq, n_samples, on_device, WALK_SERIAL)) return FXRX_ERR_HIP;
+        if (finish_front() || stitch_next()) return FXRX_ERR_HIP;
+    } else if (cont) {               // same, but the block being verified is finished first: its payload MF is the last
+        if (finish_front()) return FXRX_ERR_HIP;                                   // reader of the work buffer staged next
+        if (walk_phase(c, sl, iq, n_samples, on_device, WALK_SPEC)) return FXRX_ERR_HIP;
+        if (stitch_next()) return FXRX_ERR_HIP;
+    } else {                         // state needed and not worth speculating: run the pending blocks to the end first
+        while (!c->pending.empty()) if (advance_front(c)) return FXRX_ERR_HIP;
+        if (walk_phase(c, sl, iq, n_samples, on_device, WALK_SERIAL)) return FXRX_ERR_HIP;
+    }
     while (c->pending.size() >= 2) if (advance_front(c)) return FXRX_ERR_HIP;     // (never more than one block behind the one being verified)
     c->pending.push_back(&sl);
     sl.busy = true;

@@ -389,3 +389,33 @@ def test_independent_captures_overlap_their_walks_exactly(fx, oracle):
     for _ in parts:
         cont += [key(g) for g in ctx.results(ctx.collect_raw())]
     assert cont == alone[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("on_device", [True, False])
+def test_continuing_stream_is_walked_speculatively_across_blocks(fx, oracle, on_device):
+    """Big blocks of ONE continuing stream, several in flight: the speculative walkers of block k+1 are launched before
+    block k is stitched, its true walker joins them once block k's tail and resume state are known.  Frames (absolute
+    positions included) must be exactly those of a single pass / of the sequential oracle, whatever the cut."""
+    import torch
+    x, inj = fx.synth_stream(1_900_000, stream_id=77, payload_len=300, gap=200)
+    key = lambda g: (g["start"], g["payload"], g["payload_valid"], g["evm_sum"], g["rxy"], g["header_valid"])
+    one = fx.RxContext(1, want_framesyms=True)
+    ref = one.process([x]); one.close()
+    compare_frames(oracle_frames(oracle, x), ref)
+    for cuts in ([0, 300_000, 650_123, 950_000, 1_300_777, 1_600_000, len(x)], [0, 400_000, 800_000, 1_000_000, 1_100_000, 1_500_000, len(x)]):
+        parts = [np.ascontiguousarray(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+        keep = [torch.from_numpy(p).cuda() for p in parts] if on_device else parts
+        ctx = fx.RxContext(1)
+        ctx.set_depth(3)
+        got, inflight = [], 0
+        for p in keep:
+            if inflight == 3:
+                got += ctx.results(ctx.collect_raw()); inflight -= 1
+            if on_device: ctx.submit_raw([p.data_ptr()], [p.numel()], True)
+            else: ctx.submit_raw([p.ctypes.data], [len(p)], False)
+            inflight += 1
+        while inflight:
+            got += ctx.results(ctx.collect_raw()); inflight -= 1
+        assert [key(g) for g in got] == [key(g) for g in ref]
+        ctx.close()
