@@ -157,16 +157,18 @@ void      fxrx_reset(fxrx_ctx *c);
 int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
 int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out);
 
-/* Pipelined form of fxrx_process (= submit + collect).  fxrx_submit launches the walk of the block and then
- * completes the PREVIOUS submitted block (waits for its walkers, stitches its frames, queues its payload stages);
- * fxrx_collect waits for the OLDEST submitted block (completing it first if nobody has) and exposes its results
- * through fxrx_result / fxrx_last_timing.  With depth d (fxrx_set_depth, 1..16, default 1) up to d blocks may be in
- * flight, each on its own payload stream when FXRX_PAYLOAD_STREAMS allows.  A block that continues the streams of
- * the previous one needs the state that block leaves behind, so the previous block is completed before the new
- * walk is launched; after fxrx_reset the blocks are independent and the new walk is launched first (device input
- * only).  Blocks of one stream must be submitted in order; device input buffers must stay valid until their block
- * has been collected; results stay valid until the next fxrx_collect / fxrx_process on the context.  Returns 0
- * (submit) / result count (collect) or FXRX_ERR_*. */
+/* Pipelined form of fxrx_process (= submit + collect).  fxrx_submit launches the walkers of the new block and runs
+ * one host phase each of the (at most two) blocks submitted before it: the older one gets its payload stages queued,
+ * the younger one is stitched and its seek verification launched.  fxrx_collect waits for the OLDEST submitted block
+ * (running its remaining host phases first if nobody has) and exposes its results through fxrx_result /
+ * fxrx_last_timing.  With depth d (fxrx_set_depth, 1..16, default 1) up to d blocks may be in flight, each on its own
+ * payload stream.  After fxrx_reset a block is independent of the ones before it and is walked at once; a block that
+ * continues the streams of the previous one is walked speculatively (blocks of >= 2^18 samples per stream, <= 8
+ * streams: all but the first walker of each stream start at once, the first joins when the previous block's tail is
+ * known) or, when small, only after the previous block has run all its host phases.  Blocks of one stream must be
+ * submitted in order; device input buffers must stay valid until their block has been collected; results stay valid
+ * until the next fxrx_collect / fxrx_process on the context.  Returns 0 (submit) / result count (collect) or
+ * FXRX_ERR_*. */
 int fxrx_set_depth(fxrx_ctx *c, unsigned int depth);
 int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
 int fxrx_collect(fxrx_ctx *c);
