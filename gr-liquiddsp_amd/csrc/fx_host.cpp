@@ -450,7 +450,7 @@ static int walk_phase(fxrx_ctx_s *c, Slot &sl, const void *const *iq, const uint
         if (nn) HIP_OK(hipMemcpyAsync(W.p + lead, iq[s], nn * sizeof(float2), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, sl.stream_w));
         xs[s] = W.p; ns[s] = (int64_t)(lead + nn); sl.base[s] = total_before - (int64_t)lead; sl.wbuf[s] = b;
     }
-    sl.timing.samples = total_new;
+    sl.timing.samples = total_new; sl.timing.walk_mode = (uint64_t)mode;
 
     // ---- 2. walk jobs: cut every stream into segments ----
     uint64_t seg = c->cfg.segment_len;

@@ -185,7 +185,8 @@ typedef struct {
     double   host_submit_ms, host_walkwait_ms;   /* wall time spent inside fxrx_submit / of that, waiting for the walker + seek verification */
     double   seekverify_ms;                      /* fx_seekverify_kernel (full detector over the hops the walkers skipped) */
     uint64_t verify_hops, verify_failures;
-    double   host_collectwait_ms;                /* wall time fxrx_collect waited for the block's results */       /* hops re-checked / streams walked again because a skipped hop fired */
+    double   host_collectwait_ms;                /* wall time fxrx_collect waited for the block's results */
+    uint64_t walk_mode;                          /* 0 walked with known state, 1 speculatively across the block boundary, 2 re-staged */       /* hops re-checked / streams walked again because a skipped hop fired */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
 /* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */

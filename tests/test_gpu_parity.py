@@ -418,4 +418,38 @@ def test_continuing_stream_is_walked_speculatively_across_blocks(fx, oracle, on_
         while inflight:
             got += ctx.results(ctx.collect_raw()); inflight -= 1
         assert [key(g) for g in got] == [key(g) for g in ref]
+        assert ctx.timing()["walk_mode"] == 1                     # the last block was walked speculatively
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_speculative_blocks_multi_stream_and_tail_longer_than_headroom(fx, oracle):
+    """Cross-block speculation with several streams of different block sizes, and with frames long enough (about 260 k
+    samples) that the tail carried over a cut exceeds the staging headroom: that block is re-staged and walked serially.
+    Everything must still equal the single pass."""
+    key = lambda g: (g["stream"], g["start"], g["payload"], g["payload_valid"], g["evm_sum"], g["rxy"], g["header_valid"])
+    # stream 0: short frames first (small tails -> small headroom), then PSK2 r1/2 frames of about 260 k samples: the cut at
+    # 700 k falls 150 k samples into the first of them
+    xs = [np.concatenate([fx.synth_stream(550_000, stream_id=84, payload_len=64)[0],
+                          fx.synth_stream(850_000, stream_id=81, payload_len=8000, mod=1, fec0=11, gap=3000)[0]]),
+          fx.synth_stream(1_150_000, stream_id=82, payload_len=500, mod=27, fec0=15)[0],
+          fx.synth_stream(1_300_000, stream_id=83, payload_len=64, mod=2, fec0=1)[0]]
+    one = fx.RxContext(3)
+    ref = [key(g) for g in one.process(xs)]; one.close()
+    compare_frames(oracle_frames(oracle, xs[0]), [g for g in fx.RxContext(3, want_framesyms=True).process(xs) if g["stream"] == 0])
+    assert len([r for r in ref if r[0] == 0 and len(r[2]) == 8000]) >= 2
+    nblk = 4
+    cuts = [[int(len(x) * k / nblk) + (137 * s if 0 < k < nblk else 0) for k in range(nblk + 1)] for s, x in enumerate(xs)]
+    ctx = fx.RxContext(3)
+    ctx.set_depth(3)
+    got, inflight, parts_alive, modes = [], 0, [], []
+    for k in range(nblk):
+        parts = [np.ascontiguousarray(x[cuts[s][k]:cuts[s][k + 1]]) for s, x in enumerate(xs)]
+        parts_alive.append(parts)
+        if inflight == 3:
+            got += ctx.results(ctx.collect_raw()); modes.append(ctx.timing()["walk_mode"]); inflight -= 1
+        ctx.submit_raw([p.ctypes.data for p in parts], [len(p) for p in parts], False); inflight += 1
+    while inflight:
+        got += ctx.results(ctx.collect_raw()); modes.append(ctx.timing()["walk_mode"]); inflight -= 1
+    assert sorted(key(g) for g in got) == sorted(ref)
+    assert modes[0] == 0 and 2 in modes, "expected the first block serial and at least one re-staged block, got %r" % modes
