@@ -47,6 +47,17 @@ template <int WW> struct WalkLdsT {
     uint8_t b0[64], b1[64];
 };
 
+// what one detector hop needs, and nothing else: the seek verifier's workgroups (30 KB) leave LDS for the single-wave
+// PLL workgroups of the blocks in flight -- with the walker's 53-KB layout three verifier workgroups fill a CU's LDS
+// and PLL grids, the longest stage of a block, queue behind them.
+template <int WW> struct SeekLdsT {
+    static constexpr int WAVES = WW;
+    float2 win[FX_NFFT], X[FX_NFFT], S[FX_NFFT];
+    float2 scr[WW][576];
+    float  redf[WW < 4 ? 4 : WW]; float2 redc[WW < 4 ? 4 : WW];
+    float  redv[WW]; uint32_t redk[WW];
+};
+
 // ---- workgroup reductions (all 256 threads call; result on every thread) ----
 template <class LDS> __device__ __forceinline__ float block_sum256(float v, LDS &L, int lane, int wave)
 {
@@ -670,11 +681,11 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t 
 // on the strength of its coarse scan).  Hops are independent given (pos, floor), so the runs are cut to spread over
 // the whole chip; the workgroup slides its window exactly like the walker does.
 template <int WW>
-__global__ __launch_bounds__(64 * WW, WW == 4 ? 3 : FX_DETECT_OCC)      // 4-wave workgroups: LDS allows three per CU
+__global__ __launch_bounds__(64 * WW, FX_DETECT_OCC)
 void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
 {
     constexpr int WALK_THREADS = 64 * WW;
-    __shared__ WalkLdsT<WW> L;
+    __shared__ SeekLdsT<WW> L;
     const FxVerifyJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 twA[7], twB[7];
