@@ -121,7 +121,8 @@ struct Slot {
     std::vector<FxWalkJob> jobs; std::vector<uint32_t> job_stream;
     PinBuf<FxWalkResult> h_res; PinBuf<FxFrame> h_frames; PinBuf<FxWalkJob> hp_jobs;
     PinBuf<FxVerifyJob> hp_vjobs; PinBuf<FxVerifyResult> h_vres;
-    hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr, ev_v0 = nullptr, ev_v1 = nullptr, ev_carry = nullptr;
+    hipEvent_t ev_w0 = nullptr, ev_w1 = nullptr, ev_v0 = nullptr, ev_v1 = nullptr, ev_carry = nullptr, ev_j0 = nullptr;
+    bool wait_j0 = false;                // true walkers were launched on the priority stream: ev_j0 marks their end
     unsigned index = 0;                  // position in the ring of slots
     hipStream_t stream_w = nullptr;      // the walk stream this block uses (borrowed)
     std::vector<const float2 *> xs; std::vector<int64_t> ns; std::vector<size_t> first_job;
@@ -228,13 +229,14 @@ const PlanDev &get_plan(fxrx_ctx_s *c, unsigned n, unsigned check, unsigned fec0
 // slots continues through the FX_EXIT_TABLE_FULL path.
 inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 2048 + 8, 512); }
 
-int launch_walk(fxrx_ctx_s *c, Slot &sl, size_t first, size_t count)
+int launch_walk(fxrx_ctx_s *c, Slot &sl, size_t first, size_t count, hipStream_t st = nullptr)
 {
+    if (!st) st = sl.stream_w;
     // Job descriptors, per-job results and frame tables live in pinned host memory that the kernel addresses
     // directly: each workgroup reads one descriptor and writes a handful of 128-byte records, so the PCIe hop costs
     // less than the three staging copies it replaces on the walk -> stitch critical path.
     std::memcpy(sl.hp_jobs.p + first, sl.jobs.data() + first, count * sizeof(FxWalkJob));
-    HIP_OK(fx_launch_walk(sl.jobs[first].mode, (unsigned)count, sl.stream_w, sl.hp_jobs.p + first, sl.h_res.p + first, sl.h_frames.p, c->d_tables));
+    HIP_OK(fx_launch_walk(sl.jobs[first].mode, (unsigned)count, st, sl.hp_jobs.p + first, sl.h_res.p + first, sl.h_frames.p, c->d_tables));
     return 0;
 }
 
@@ -265,8 +267,8 @@ static int ensure_pstreams(fxrx_ctx_s *c, unsigned want)
 static int make_slot(fxrx_ctx_s *c)
 {
     std::unique_ptr<Slot> s(new Slot);
-    hipEvent_t *ev[12] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll0, &s->ev_pll1, &s->ev_dec0, &s->ev_dec1, &s->ev_done,
-                           &s->ev_w0, &s->ev_w1, &s->ev_v0, &s->ev_v1, &s->ev_carry };
+    hipEvent_t *ev[13] = { &s->ev_mf0, &s->ev_mf1, &s->ev_pll0, &s->ev_pll1, &s->ev_dec0, &s->ev_dec1, &s->ev_done,
+                           &s->ev_w0, &s->ev_w1, &s->ev_v0, &s->ev_v1, &s->ev_carry, &s->ev_j0 };
     for (auto e : ev) HIP_OK(hipEventCreate(e));
     s->index = (unsigned)c->slots.size();
     s->stream_p = c->stream_p[c->slots.size() % c->n_pstreams]; s->stream_d = s->stream_p;
@@ -348,7 +350,7 @@ void fxrx_destroy(fxrx_ctx *c)
     (void)hipSetDevice(c->cfg.device);
     sync_all(c);
     for (auto &s : c->slots) {
-        hipEvent_t ev[12] = { s->ev_mf0, s->ev_mf1, s->ev_pll0, s->ev_pll1, s->ev_dec0, s->ev_dec1, s->ev_done, s->ev_w0, s->ev_w1, s->ev_v0, s->ev_v1, s->ev_carry };
+        hipEvent_t ev[13] = { s->ev_mf0, s->ev_mf1, s->ev_pll0, s->ev_pll1, s->ev_dec0, s->ev_dec1, s->ev_done, s->ev_w0, s->ev_w1, s->ev_v0, s->ev_v1, s->ev_carry, s->ev_j0 };
         for (auto e : ev) if (e) (void)hipEventDestroy(e);
     }
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -587,6 +589,45 @@ static int stitch_stream(fxrx_ctx_s *c, Slot &sl, unsigned s)
     }
 }
 
+// Speculative block of a continuing stream, once the previous block is finished (its tail and resume state are known):
+// put the tail in front of the new samples and launch every stream's true walker (job 0).  Called as early as possible
+// -- before the next block's speculative walkers are launched -- so that these few workgroups find free CUs at once.
+static int launch_true_walkers(fxrx_ctx_s *c, Slot &sl)
+{
+    if (!sl.late0) return 0;
+    const unsigned NS = c->cfg.n_streams;
+    std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns;
+    {
+        // Speculative block of a continuing stream: the previous block is finished by now, so the tail and the resume
+        // state are known.  Put the tail in front of the new samples and launch every stream's true walker (job 0).
+        bool fits = true;
+        for (unsigned s = 0; s < NS; s++) if ((int64_t)c->st[s].carry_len > sl.headroom) fits = false;
+        if (!fits) {                                  // (rare) a tail longer than the headroom: stage and walk again, serially
+            HIP_OK(hipEventSynchronize(sl.ev_w1));
+            if (walk_phase(c, sl, sl.in_ptr.data(), sl.in_n.data(), sl.in_dev, WALK_RESTAGE)) return FXRX_ERR_HIP;
+        } else {
+            // (a separate highest-priority stream for these few workgroups was tried: no measurable difference)
+            hipStream_t st = sl.stream_w;
+            for (unsigned s = 0; s < NS; s++) {
+                StreamState &S = c->st[s];
+                const int64_t c0 = sl.headroom - (int64_t)S.carry_len;          // coordinate of tail sample 0
+                if (S.carry_len) {
+                    if (S.carry_ev) HIP_OK(hipStreamWaitEvent(st, S.carry_ev, 0));
+                    HIP_OK(hipMemcpyAsync(const_cast<float2 *>(xs[s]) + c0, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, st));
+                }
+                FxWalkJob &j = sl.jobs[sl.first_job[s]];
+                j.start = c0 + S.pos; j.floor = c0 + S.floor_; j.fresh = S.fresh ? 1u : 0u;
+                j.handoff = j.stop < ns[s] ? 1u : 0u;
+                if (launch_walk(c, sl, sl.first_job[s], 1, st)) return FXRX_ERR_HIP;
+            }
+            HIP_OK(hipEventRecord(sl.ev_j0, st));
+            sl.wait_j0 = true;
+            sl.late0 = false;
+        }
+    }
+    return 0;
+}
+
 // ---- phase 2: wait for the walkers, stitch every stream's chain, launch the seek verification ----
 static int stitch_phase(fxrx_ctx_s *c, Slot &sl)
 {
@@ -596,35 +637,12 @@ static int stitch_phase(fxrx_ctx_s *c, Slot &sl)
     std::vector<const float2 *> &xs = sl.xs; std::vector<int64_t> &ns = sl.ns;
     for (auto &w : c->walk_stamp) w = 0;
     c->walk_stamp_max = 0;
-    if (sl.late0) {
-        // Speculative block of a continuing stream: the previous block is finished by now, so the tail and the resume
-        // state are known.  Put the tail in front of the new samples and launch every stream's true walker (job 0).
-        bool fits = true;
-        for (unsigned s = 0; s < NS; s++) if ((int64_t)c->st[s].carry_len > sl.headroom) fits = false;
-        if (!fits) {                                  // (rare) a tail longer than the headroom: stage and walk again, serially
-            HIP_OK(hipEventSynchronize(sl.ev_w1));
-            if (walk_phase(c, sl, sl.in_ptr.data(), sl.in_n.data(), sl.in_dev, WALK_RESTAGE)) return FXRX_ERR_HIP;
-        } else {
-            for (unsigned s = 0; s < NS; s++) {
-                StreamState &S = c->st[s];
-                const int64_t c0 = sl.headroom - (int64_t)S.carry_len;          // coordinate of tail sample 0
-                if (S.carry_len) {
-                    if (S.carry_ev) HIP_OK(hipStreamWaitEvent(sl.stream_w, S.carry_ev, 0));
-                    HIP_OK(hipMemcpyAsync(const_cast<float2 *>(xs[s]) + c0, S.carry[S.cur].p, S.carry_len * sizeof(float2), hipMemcpyDeviceToDevice, sl.stream_w));
-                }
-                FxWalkJob &j = sl.jobs[sl.first_job[s]];
-                j.start = c0 + S.pos; j.floor = c0 + S.floor_; j.fresh = S.fresh ? 1u : 0u;
-                j.handoff = j.stop < ns[s] ? 1u : 0u;
-                if (launch_walk(c, sl, sl.first_job[s], 1)) return FXRX_ERR_HIP;
-            }
-            HIP_OK(hipEventRecord(sl.ev_w1, sl.stream_w));
-            sl.late0 = false;
-        }
-    }
+    if (launch_true_walkers(c, sl)) return FXRX_ERR_HIP;
     {
         // (events, not the stream: the walk of the block after next may already be queued behind this one's)
         const auto tw = std::chrono::steady_clock::now();
         HIP_OK(hipEventSynchronize(sl.ev_w1));
+        if (sl.wait_j0) { HIP_OK(hipEventSynchronize(sl.ev_j0)); HIP_OK(hipStreamWaitEvent(sl.stream_w, sl.ev_j0, 0)); sl.wait_j0 = false; }
         sl.timing.host_walkwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
     }
     sl.chains.assign(NS, Chain{});
@@ -871,6 +889,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         if (finish_front() || stitch_next()) return FXRX_ERR_HIP;
     } else if (cont) {               // same, but the block being verified is finished first: its payload MF is the last
         if (finish_front()) return FXRX_ERR_HIP;                                   // reader of the work buffer staged next
+        for (Slot *p : c->pending) if (p->stage == Slot::WALKING) { if (launch_true_walkers(c, *p)) return FXRX_ERR_HIP; break; }
         if (walk_phase(c, sl, iq, n_samples, on_device, WALK_SPEC)) return FXRX_ERR_HIP;
         if (stitch_next()) return FXRX_ERR_HIP;
     } else {                         // state needed and not worth speculating: run the pending blocks to the end first
