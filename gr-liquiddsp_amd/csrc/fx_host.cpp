@@ -360,11 +360,20 @@ void fxrx_destroy(fxrx_ctx *c)
     delete c;
 }
 
-// forget all per-stream state (position, carried tail).  In-flight blocks are unaffected (a block submitted before
-// the reset no longer writes its resume state back: the epoch tells).
+static int advance_front(fxrx_ctx_s *c);
+
+// forget all per-stream state (position, carried tail).  In-flight blocks are unaffected: a block submitted before the
+// reset no longer writes its resume state back (the epoch tells), and a pending speculative block, whose true walker
+// still needs the state its predecessor leaves behind, is run through its host phases first.
 void fxrx_reset(fxrx_ctx *c)
 {
     if (!c) return;
+    bool needs_state = false;
+    for (Slot *p : c->pending) if (p->late0) needs_state = true;
+    if (needs_state) {
+        (void)hipSetDevice(c->cfg.device);
+        while (!c->pending.empty()) if (advance_front(c)) break;
+    }
     c->epoch++;
     for (auto &s : c->st) { s.carry_len = 0; s.total = 0; s.pos = 0; s.floor_ = 0; s.fresh = true; s.carry_ev = nullptr; }
     // (work-buffer guards stay: blocks in flight may still be reading them)
@@ -851,12 +860,13 @@ static int finish_phase(fxrx_ctx_s *c, Slot &sl)
     return 0;
 }
 
-// A block goes through walk_phase, stitch_phase, finish_phase.  The last two need the host, and the walk of block k+1
-// needs the stream state block k leaves behind -- unless the streams were reset in between (independent captures, the
-// bench's passes).  Then the host never has to wait: a submit launches the new block's walk, finishes the block
-// whose verification was launched by the previous submit, and stitches the block whose walk was launched by the
-// previous submit (launching its verification).  A continuing stream runs all three phases of block k before it
-// walks block k+1.
+// A block goes through walk_phase, stitch_phase, finish_phase.  The last two need the host, and the true walker of
+// block k+1 needs the stream state block k leaves behind.  The host is software-pipelined so that it does not wait for
+// kernels it has just launched: a submit launches the new block's walkers, finishes the block whose verification was
+// launched by the previous submit, and stitches the block whose walkers were launched by the previous submit
+// (launching its verification).  That works when the new block is independent of the pending ones (the streams were
+// reset in between: separate captures, the bench's passes) and, through cross-block speculation (WALK_SPEC), for big
+// blocks of a continuing stream; small continuing blocks run the pending blocks to the end first.
 static int advance_front(fxrx_ctx_s *c)          // one phase of the oldest pending block
 {
     Slot *p = c->pending.front();
@@ -930,7 +940,7 @@ int fxrx_collect(fxrx_ctx *c)
         (void)hipEventElapsedTime(&ms, sl.ev_dec0, sl.ev_dec1); sl.timing.paydec_ms = ms;
     }
     sl.timing.total_ms = sl.timing.walk_ms + sl.timing.seekverify_ms + sl.timing.paymf_ms + sl.timing.paypll_ms + sl.timing.paydec_ms;
-    sl.busy = false; c->last = &sl;
+    sl.busy = false; sl.stage = Slot::IDLE; c->last = &sl;
     c->tail = (c->tail + 1) % c->depth; c->inflight--;
     return (int)sl.out.size();
 }

@@ -453,3 +453,32 @@ def test_speculative_blocks_multi_stream_and_tail_longer_than_headroom(fx, oracl
         got += ctx.results(ctx.collect_raw()); modes.append(ctx.timing()["walk_mode"]); inflight -= 1
     assert sorted(key(g) for g in got) == sorted(ref)
     assert modes[0] == 0 and 2 in modes, "expected the first block serial and at least one re-staged block, got %r" % modes
+
+
+@pytest.mark.gpu
+def test_reset_between_speculative_blocks(fx, oracle):
+    """fxrx_reset while speculative blocks of the old stream are still pending: they must finish with the state their
+    predecessors leave behind, and the new stream must start clean.  Reference: the same calls, one block at a time."""
+    import torch
+    xa = fx.synth_stream(900_000, stream_id=85, payload_len=350)[0]
+    xb = fx.synth_stream(800_000, stream_id=86, payload_len=120, mod=3, fec0=16)[0]
+    key = lambda g: (g["start"], g["payload"], g["payload_valid"], g["evm_sum"], g["rxy"])
+    seq = [("a", xa[:300_000]), ("a", xa[300_000:600_000]), ("a", xa[600_000:]), ("reset", None),
+           ("b", xb[:400_123]), ("b", xb[400_123:]), ("reset", None), ("a", xa[:450_000]), ("a", xa[450_000:])]
+    blocking = fx.RxContext(1)
+    ref = []
+    for tag, blk in seq:
+        if tag == "reset": blocking.reset()
+        else: ref.append([key(g) for g in blocking.process([np.ascontiguousarray(blk)])])
+    ctx = fx.RxContext(1); ctx.set_depth(4)
+    dev = [None if b is None else torch.from_numpy(np.ascontiguousarray(b)).cuda() for _, b in seq]
+    got, inflight = [], 0
+    for (tag, _), d in zip(seq, dev):
+        if tag == "reset": ctx.reset(); continue
+        if inflight == 4:
+            got.append([key(g) for g in ctx.results(ctx.collect_raw())]); inflight -= 1
+        ctx.submit_raw([d.data_ptr()], [d.numel()], True); inflight += 1
+    while inflight:
+        got.append([key(g) for g in ctx.results(ctx.collect_raw())]); inflight -= 1
+    assert got == ref
+    assert sum(len(r) for r in ref) > 300
