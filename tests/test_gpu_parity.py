@@ -482,3 +482,25 @@ def test_reset_between_speculative_blocks(fx, oracle):
         got.append([key(g) for g in ctx.results(ctx.collect_raw())]); inflight -= 1
     assert got == ref
     assert sum(len(r) for r in ref) > 300
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mod,fec0,fec1,check", [(2, 11, 1, 6), (29, 27, 6, 5), (1, 17, 10, 3)])
+def test_maximum_payload_length(fx, oracle, mod, fec0, fec1, check):
+    """The header's 16-bit length field at its maximum: one 65535-byte frame (0.15 to 1.2 M samples depending on the
+    scheme; 0.5 M trellis steps for the convolutional codes) between two short ones, against the oracle."""
+    rng = np.random.default_rng(65535 + mod)
+    g = fx.FrameGen(mod, fec0, fec1, check)
+    big = rng.integers(0, 256, 65535, dtype=np.uint8)
+    small = rng.integers(0, 256, 40, dtype=np.uint8)
+    x = _chan(np.concatenate([np.zeros(500, np.complex64), g.frame(small), np.zeros(300, np.complex64), g.frame(big),
+                              np.zeros(280, np.complex64), g.frame(small), np.zeros(1000, np.complex64)]), 0.013, -0.8, 28.0, rng)
+    g.close()
+    of = oracle_frames(oracle, x)
+    assert [len(f.payload) for f in of] == [40, 65535, 40] and all(f.payload_valid for f in of)
+    for seg in (0, 1 << 16):
+        ctx = fx.RxContext(1, want_framesyms=True, segment_len=seg)
+        gf = ctx.process([x])
+        compare_frames(of, gf)
+        assert gf[1]["payload"] == big.tobytes()
+        ctx.close()
