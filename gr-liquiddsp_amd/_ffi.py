@@ -31,6 +31,11 @@ class GenProps(C.Structure):                # flexframegenprops_s
     _fields_ = [("check", C.c_uint), ("fec0", C.c_uint), ("fec1", C.c_uint), ("mod_scheme", C.c_uint)]
 
 
+class TxFrame(C.Structure):                 # fxtx_frame
+    _fields_ = [("props", GenProps), ("header", C.c_void_p), ("payload", C.c_void_p), ("payload_len", C.c_uint),
+                ("dt", C.c_float), ("out_offset", C.c_ulonglong)]
+
+
 class Config(C.Structure):                  # fxrx_config
     _fields_ = [("device", C.c_int), ("mode", C.c_int), ("n_streams", C.c_uint), ("threshold", C.c_float),
                 ("segment_len", C.c_uint), ("want_framesyms", C.c_int)]
@@ -73,6 +78,7 @@ EXPORTS = [
     "fxrx_process", "fxrx_result", "fxrx_set_depth", "fxrx_submit", "fxrx_collect", "fxrx_debug_stamps", "fxrx_debug_walk_stamps", "fxrx_debug_walk_maxjob", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
     "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
     "fxrx_outer_from_index", "fxrx_outer_to_index",
+    "fxtx_create", "fxtx_destroy", "fxtx_frame_len", "fxtx_generate",
 ]
 
 
@@ -122,6 +128,11 @@ def lib():
     L.fxrx_last_timing.restype = C.c_int; L.fxrx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.fxrx_stream.restype = C.c_void_p; L.fxrx_stream.argtypes = [C.c_void_p]
     L.fxrx_gen_frame_len.restype = C.c_uint; L.fxrx_gen_frame_len.argtypes = [C.c_uint] * 5
+    L.fxtx_create.restype = C.c_void_p; L.fxtx_create.argtypes = [C.c_int]
+    L.fxtx_destroy.restype = None; L.fxtx_destroy.argtypes = [C.c_void_p]
+    L.fxtx_frame_len.restype = C.c_uint; L.fxtx_frame_len.argtypes = [C.POINTER(TxFrame)]
+    L.fxtx_generate.restype = C.c_int
+    L.fxtx_generate.argtypes = [C.c_void_p, C.POINTER(TxFrame), C.c_uint, C.c_void_p, C.c_ulonglong]
     for n in ("mod", "inner", "outer"):
         f = getattr(L, "fxrx_%s_from_index" % n); f.restype = C.c_int; f.argtypes = [C.c_int]
         f = getattr(L, "fxrx_%s_to_index" % n); f.restype = C.c_int; f.argtypes = [C.c_uint]

@@ -509,12 +509,11 @@ struct FrameGen {
         return bps ? (8 * p.l1 + bps - 1) / bps : 0;
     }
     unsigned frame_len(unsigned payload_len) const { return FX_K * (FX_PN_LEN + FX_HDR_SYM + payload_syms(payload_len) + 2 * FX_M); }
-    void assemble(const uint8_t *header14, const uint8_t *payload, unsigned payload_len)
+    // preamble + header symbols (FX_PN_LEN + FX_HDR_SYM of them)
+    void head(const uint8_t *header14, unsigned payload_len, cf *out) const
     {
         const HostTables &T = host_tables();
-        unsigned npay = payload_syms(payload_len);
-        syms.assign(FX_PN_LEN + FX_HDR_SYM + npay + 2 * FX_M, cf{ 0, 0 });
-        std::memcpy(syms.data(), T.pn, sizeof T.pn);
+        std::memcpy(out, T.pn, sizeof T.pn);
         uint8_t hd[FX_HDR_DEC];
         if (header14) std::memcpy(hd, header14, FX_HDR_USER); else std::memset(hd, 0, FX_HDR_USER);
         hd[14] = FX_PROTOCOL; hd[15] = (uint8_t)((payload_len >> 8) & 0xff); hd[16] = (uint8_t)(payload_len & 0xff);
@@ -524,11 +523,47 @@ struct FrameGen {
         uint8_t hs[FX_HDR_MOD]; pack_symbols(he.data(), FX_HDR_ENC, 2, FX_HDR_MOD, hs);
         Modulator qm(FX_MODEM_QPSK, T.sc);
         for (unsigned i = 0, n = 0, pp = 0; i < FX_HDR_SYM; i++)
-            syms[FX_PN_LEN + i] = (i % FX_PILOT_SPACING) == 0 ? T.pilots[pp++] : qm.mod(hs[n++]);
+            out[FX_PN_LEN + i] = (i % FX_PILOT_SPACING) == 0 ? T.pilots[pp++] : qm.mod(hs[n++]);
+    }
+    // payload symbols as the modem's input words (what pack_symbols hands to Modulator::mod)
+    std::vector<uint8_t> payload_words(const uint8_t *payload, unsigned payload_len) const
+    {
+        const unsigned npay = payload_syms(payload_len);
         PacketPlan pl = packet_plan(payload_len, check, fec0, fec1);
         std::vector<uint8_t> pe = packet_encode(pl, payload);
         std::vector<uint8_t> ps(npay + 1);
         pack_symbols(pe.data(), pl.l1, modem_bps(ms), npay, ps.data());
+        ps.resize(npay);
+        return ps;
+    }
+    // ... and as constellation indices for fx_txgen_kernel's tx_point(): Gray decoding and the DPSK phase accumulation,
+    // i.e. all the integer work of Modulator::mod, done here; the kernel does the float work
+    std::vector<uint8_t> payload_indices(const uint8_t *payload, unsigned payload_len) const
+    {
+        std::vector<uint8_t> w = payload_words(payload, payload_len);
+        const unsigned bps = modem_bps(ms);
+        unsigned acc = 0;
+        for (auto &v : w) {
+            const unsigned sym = v;
+            switch (ms) {
+            case FX_MODEM_QPSK: break;
+            case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: case FX_MODEM_ASK4: v = (uint8_t)gray_dec(sym); break;
+            case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8: acc = (acc + gray_dec(sym)) & ((1u << bps) - 1u); v = (uint8_t)acc; break;
+            default: {
+                const unsigned mq = ms == FX_MODEM_QAM64 ? 3u : 2u;
+                v = (uint8_t)((gray_dec(sym >> mq) << mq) | gray_dec(sym & ((1u << mq) - 1u)));
+            }
+            }
+        }
+        return w;
+    }
+    void assemble(const uint8_t *header14, const uint8_t *payload, unsigned payload_len)
+    {
+        const HostTables &T = host_tables();
+        unsigned npay = payload_syms(payload_len);
+        syms.assign(FX_PN_LEN + FX_HDR_SYM + npay + 2 * FX_M, cf{ 0, 0 });
+        head(header14, payload_len, syms.data());
+        std::vector<uint8_t> ps = payload_words(payload, payload_len);
         Modulator pm(ms, T.sc);
         for (unsigned i = 0; i < npay; i++) syms[FX_PN_LEN + FX_HDR_SYM + i] = pm.mod(ps[i]);
     }

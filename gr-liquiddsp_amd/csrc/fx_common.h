@@ -132,6 +132,18 @@ struct FxVerifyResult {
     uint32_t bidx; int32_t boff; float peak;
 };
 
+// ---- frame generator (fx_txgen_kernel) ----
+struct FxTxJob {
+    uint64_t out_off;       // first output sample of the frame in the destination buffer
+    uint32_t nsym;          // symbols incl. the 2m flush zeros (output = 2 nsym samples)
+    uint32_t npay;          // payload symbols
+    uint32_t ms;            // payload modulation
+    uint32_t head_off;      // offset of the frame's 295 ready-made preamble + header symbols
+    uint32_t idx_off;       // offset of its payload symbol indices (one byte each)
+    uint32_t pad_;
+    float    taps[32];      // transmit pulse (29 taps; designed with the frame's fractional delay)
+};
+
 // ---- payload stage records ----
 struct FxPayJob {           // one per valid, complete frame
     const float2 *x;        // stream base

@@ -251,6 +251,7 @@ __attribute__((constructor)) static void fxrx_default_hw_queues() { setenv("GPU_
 extern "C" {
 
 const char *fxrx_last_error(void) { return g_err.c_str(); }
+void fxrx_set_error(const char *msg) { set_err(msg ? msg : ""); }      // for the library's other translation units
 const char *fxrx_version(void) { return "fxrx 0.1 (gfx950)"; }
 int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
 

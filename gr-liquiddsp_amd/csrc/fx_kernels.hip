@@ -1399,3 +1399,79 @@ extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, unsigned wav
     else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, njobs, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
     return hipGetLastError();
 }
+
+// ===================================================================== frame generator (flex_tx counterpart)
+// One thread per symbol n of a frame: constellation point of the symbol (preamble / header symbols come ready-made
+// from the host, payload symbols as indices -- the bit packing, and for DPSK the running phase index, are byte work
+// done while the packet is encoded), then the two output samples y[2n+i] = sum_t h[i+2t] x[n-t], t ascending,
+// exactly as the host generator and the oracle accumulate them.  Symbols are staged through LDS (256 + 14 per tile).
+#define TX_TILE 256
+__device__ __forceinline__ float2 tx_point(unsigned ms, unsigned v, const float2 *sc)
+{
+    const unsigned bps = modem_bps(ms);
+    switch (ms) {
+    case FX_MODEM_QPSK: { const float h = 0.70710678118654752f; return make_float2((v & 1) ? -h : h, (v & 2) ? -h : h); }
+    case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16:
+    case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8:          // v is the phase index (Gray-decoded, accumulated)
+        if (bps <= 2) {
+            const unsigned q = bps == 1 ? 2u * (v & 1u) : (v & 3u);
+            return make_float2(q == 0 ? 1.0f : (q == 2 ? -1.0f : 0.0f), q == 1 ? 1.0f : (q == 3 ? -1.0f : 0.0f));
+        }
+        return sc[(v << (32 - bps)) >> 22];
+    case FX_MODEM_ASK4: return make_float2((2.0f * (float)v - 3.0f) * 0.447213595f, 0.0f);   // v Gray-decoded
+    default: {                                                                                  // v = si << mq | sq, Gray-decoded
+        unsigned mi, mq; float al;
+        if (ms == FX_MODEM_QAM16) { mi = 2; mq = 2; al = 0.316227766f; }
+        else if (ms == FX_MODEM_QAM32) { mi = 3; mq = 2; al = 0.196116135f; }
+        else { mi = 3; mq = 3; al = 0.154303350f; }
+        const unsigned si = v >> mq, sq = v & ((1u << mq) - 1u);
+        return make_float2((2.0f * (float)si - (float)((1u << mi) - 1u)) * al, (2.0f * (float)sq - (float)((1u << mq) - 1u)) * al);
+    }
+    }
+}
+
+extern "C" __global__ __launch_bounds__(TX_TILE)
+void fx_txgen_kernel(const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0, const float2 *head_syms, const uint8_t *pay_idx,
+                     const float2 *sc, float2 *out)
+{
+    __shared__ float2 xs[TX_TILE + 14];
+    __shared__ float h[32];
+    const FxTxJob job = jobs[tile_job[blockIdx.x]];
+    const uint32_t n0 = tile_n0[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < 29) h[tid] = job.taps[tid];
+    const uint32_t nhead = FX_PN_LEN + FX_HDR_SYM;
+    for (int i = tid; i < TX_TILE + 14; i += TX_TILE) {
+        const int64_t n = (int64_t)n0 - 14 + i;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (n >= 0 && n < (int64_t)nhead) v = head_syms[(size_t)job.head_off + (size_t)n];
+        else if (n >= (int64_t)nhead && n < (int64_t)(nhead + job.npay)) v = tx_point(job.ms, pay_idx[(size_t)job.idx_off + (size_t)(n - nhead)], sc);
+        xs[i] = v;
+    }
+    __syncthreads();
+    const uint32_t n = n0 + tid;
+    if (n >= job.nsym) return;
+    float2 y[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 15; t++) {
+            const int hi = i + 2 * t;
+            if (hi > 28 || (uint32_t)t > n) continue;
+            const float2 w = xs[tid + 14 - t];
+            ar = fmaf(h[hi], w.x, ar); ai = fmaf(h[hi], w.y, ai);
+        }
+        y[i] = make_float2(ar, ai);
+    }
+    float4 *o = reinterpret_cast<float4 *>(out + job.out_off + 2ull * n);       // out_off is even: 16-byte aligned
+    if ((job.out_off & 1ull) == 0) *o = make_float4(y[0].x, y[0].y, y[1].x, y[1].y);
+    else { out[job.out_off + 2ull * n] = y[0]; out[job.out_off + 2ull * n + 1] = y[1]; }
+}
+
+extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0,
+                                      const float2 *head_syms, const uint8_t *pay_idx, const float2 *sc, float2 *out)
+{
+    hipLaunchKernelGGL(fx_txgen_kernel, dim3(ntiles), dim3(TX_TILE), 0, st, jobs, tile_job, tile_n0, head_syms, pay_idx, sc, out);
+    return hipGetLastError();
+}

@@ -1,0 +1,129 @@
+// fx_tx.cpp -- batched frame generator on the GPU (the flex_tx counterpart: SURVEY section 8(f)-1).
+//
+// Replaces, for many frames at once, what /root/reference/lib/flex_tx_impl.cc:191-209 (send_pkt) does per PDU:
+// flexframegen_assemble (:200) + flexframegen_write_samples (:203-205) with the properties set at :51-56 / :183-189.
+// Byte work (CRC, FEC encoders, interleavers, whitening, bit packing, Gray / DPSK index arithmetic) stays on the host
+// (fx_codec.hpp: it is a few kilobytes per frame); modulation and the pulse-shaping interpolator -- all of the float
+// work, 2 x 15 fused multiply-adds per output sample -- run in fx_txgen_kernel, bit-identical to the host generator
+// behind flexframegen_* (fx_dropin.cpp) and to the oracle's fxr_gen_frame.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <memory>
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+#include "../../include/fxrx.h"
+#include "fx_common.h"
+#include "fx_codec.hpp"
+
+extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0,
+                                      const float2 *head_syms, const uint8_t *pay_idx, const float2 *sc, float2 *out);
+extern "C" void fxrx_set_error(const char *msg);       // fx_host.cpp: thread-local message behind fxrx_last_error()
+
+namespace {
+template <class T> struct Dev {
+    T *p = nullptr; size_t cap = 0;
+    bool reserve(size_t n) { if (n <= cap) return true; if (p) (void)hipFree(p); p = nullptr; cap = 0; if (hipMalloc((void **)&p, n * sizeof(T)) != hipSuccess) return false; cap = n; return true; }
+    ~Dev() { if (p) (void)hipFree(p); }
+};
+}  // namespace
+
+struct fxtx_ctx_s {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev<float2> d_sc, d_head; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
+};
+
+extern "C" {
+
+fxtx_ctx *fxtx_create(int device)
+{
+    int nd = 0;
+    if (hipGetDeviceCount(&nd) != hipSuccess || nd <= 0 || device < 0 || device >= nd) { fxrx_set_error("fxtx_create: no usable HIP device (this library has no CPU path)"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { fxrx_set_error("hipSetDevice failed"); return nullptr; }
+    std::unique_ptr<fxtx_ctx_s> c(new fxtx_ctx_s);
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fxrx_set_error("hipStreamCreate failed"); return nullptr; }
+    const fx::HostTables &H = fx::host_tables();
+    if (!c->d_sc.reserve(1024) || hipMemcpy(c->d_sc.p, H.sc, 1024 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) { fxrx_set_error("fxtx_create: table upload failed"); return nullptr; }
+    return c.release();
+}
+
+void fxtx_destroy(fxtx_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    delete c;
+}
+
+unsigned int fxtx_frame_len(const fxtx_frame *f)
+{
+    if (!f) return 0;
+    fx::FrameGen g; g.ms = f->props.mod_scheme; g.check = f->props.check; g.fec0 = f->props.fec0; g.fec1 = f->props.fec1;
+    return g.frame_len(f->payload_len);
+}
+
+int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, void *out_device, unsigned long long out_len)
+{
+    if (!c || (!frames && n_frames) || !out_device) { fxrx_set_error("fxtx_generate: null argument"); return FXRX_ERR_ARG; }
+    if (hipSetDevice(c->device) != hipSuccess) { fxrx_set_error("hipSetDevice failed"); return FXRX_ERR_HIP; }
+    const unsigned nhead = FX_PN_LEN + FX_HDR_SYM;
+    std::vector<FxTxJob> jobs(n_frames);
+    std::vector<float2> head((size_t)n_frames * nhead);
+    std::vector<uint8_t> idx; std::vector<uint32_t> tile_job, tile_n0;
+    const fx::HostTables &H = fx::host_tables();
+    // pass 1 (serial, cheap): sizes and offsets.  pass 2 (host threads): the byte work of every frame -- CRC, FEC
+    // encoders, interleavers, whitening, bit packing, Gray / DPSK index arithmetic -- a few kilobytes each.
+    uint64_t idx_total = 0;
+    for (unsigned i = 0; i < n_frames; i++) {
+        const fxtx_frame &f = frames[i];
+        if (fx::modem_bps(f.props.mod_scheme) == 0 || f.payload_len > 65535u || (!f.payload && f.payload_len)) { fxrx_set_error("fxtx_generate: bad frame description"); return FXRX_ERR_ARG; }
+        fx::FrameGen g; g.ms = f.props.mod_scheme; g.check = f.props.check; g.fec0 = f.props.fec0; g.fec1 = f.props.fec1;
+        FxTxJob &j = jobs[i];
+        std::memset(&j, 0, sizeof j);
+        j.npay = g.payload_syms(f.payload_len);
+        j.nsym = nhead + j.npay + 2 * FX_M;
+        j.ms = f.props.mod_scheme; j.out_off = f.out_offset;
+        if (f.out_offset + 2ull * j.nsym > out_len) { fxrx_set_error("fxtx_generate: frame does not fit the output buffer"); return FXRX_ERR_ARG; }
+        j.head_off = i * nhead; j.idx_off = (uint32_t)idx_total;
+        idx_total += j.npay;
+        for (uint32_t n0 = 0; n0 < j.nsym; n0 += 256) { tile_job.push_back(i); tile_n0.push_back(n0); }
+    }
+    if (idx_total >= (1ull << 32)) { fxrx_set_error("fxtx_generate: batch too large"); return FXRX_ERR_ARG; }
+    idx.assign((size_t)idx_total + 16, 0);
+    (void)fx::block_codes();                                        // build the shared code tables before the threads start
+    auto encode_range = [&](unsigned first, unsigned step) {
+        for (unsigned i = first; i < n_frames; i += step) {
+            const fxtx_frame &f = frames[i];
+            fx::FrameGen g; g.ms = f.props.mod_scheme; g.check = f.props.check; g.fec0 = f.props.fec0; g.fec1 = f.props.fec1;
+            FxTxJob &j = jobs[i];
+            g.head(f.header, f.payload_len, reinterpret_cast<fx::cf *>(head.data() + (size_t)i * nhead));
+            const std::vector<uint8_t> w = g.payload_indices(f.payload, f.payload_len);
+            std::memcpy(idx.data() + j.idx_off, w.data(), w.size());
+            if (f.dt != 0.0f) fx::design_arkaiser(FX_K, FX_M, FX_BETA, f.dt, j.taps); else std::memcpy(j.taps, H.txh, sizeof H.txh);
+        }
+    };
+    const unsigned nthr = std::max(1u, std::min({ 16u, std::thread::hardware_concurrency(), n_frames / 8u }));
+    if (nthr <= 1) encode_range(0, 1);
+    else {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthr; t++) pool.emplace_back(encode_range, t, nthr);
+        for (auto &t : pool) t.join();
+    }
+    if (n_frames == 0) return 0;
+    const size_t nt = tile_job.size();
+    if (!c->d_jobs.reserve(n_frames) || !c->d_head.reserve(head.size()) || !c->d_idx.reserve(idx.size()) || !c->d_tiles.reserve(2 * nt)) { fxrx_set_error("hipMalloc failed"); return FXRX_ERR_HIP; }
+    bool ok = hipMemcpyAsync(c->d_jobs.p, jobs.data(), n_frames * sizeof(FxTxJob), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->d_head.p, head.data(), head.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->d_idx.p, idx.data(), idx.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->d_tiles.p, tile_job.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->d_tiles.p + nt, tile_n0.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_head.p, c->d_idx.p, c->d_sc.p, (float2 *)out_device) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;       // the staging vectors above are pageable and die with this call
+    if (!ok) { fxrx_set_error(std::string("fxtx_generate: ") .append(hipGetErrorString(hipGetLastError())).c_str()); return FXRX_ERR_HIP; }
+    return 0;
+}
+
+}  // extern "C"

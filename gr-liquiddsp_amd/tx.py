@@ -49,6 +49,49 @@ class FrameGen:
     __del__ = close
 
 
+class TxContext:
+    """Batched frame generator on the GPU (fxtx_* in include/fxrx.h): many frames, one call, straight into a device
+    buffer.  Samples are bit-identical to FrameGen.frame()."""
+
+    def __init__(self, device=0):
+        self.L = _ffi.lib()
+        self.h = self.L.fxtx_create(int(device))
+        if not self.h:
+            raise RuntimeError("fxtx_create: " + self.L.fxrx_last_error().decode())
+
+    @staticmethod
+    def _desc(fr, keep):
+        t = _ffi.TxFrame()
+        t.props = _ffi.GenProps(fr.get("check", CRC_24), fr.get("fec0", 11), fr.get("fec1", 1), fr.get("mod", 2))
+        pl = np.ascontiguousarray(fr["payload"], dtype=np.uint8); keep.append(pl)
+        t.payload = pl.ctypes.data if len(pl) else None; t.payload_len = len(pl)
+        if fr.get("header") is not None:
+            hd = np.ascontiguousarray(fr["header"], dtype=np.uint8); assert len(hd) == 14; keep.append(hd); t.header = hd.ctypes.data
+        t.dt = float(fr.get("dt", 0.0)); t.out_offset = int(fr.get("offset", 0))
+        return t
+
+    def frame_len(self, fr):
+        keep = []
+        t = self._desc(fr, keep)
+        return int(self.L.fxtx_frame_len(C.byref(t)))
+
+    def generate(self, frames, out_ptr, out_len):
+        """frames: dicts with payload, offset and optionally mod, fec0, fec1, check, header, dt.  out_ptr: device pointer to
+        out_len complex64 samples (e.g. torch_tensor.data_ptr())."""
+        keep = []
+        arr = (_ffi.TxFrame * len(frames))(*[self._desc(fr, keep) for fr in frames])
+        r = self.L.fxtx_generate(self.h, arr, len(frames), C.c_void_p(int(out_ptr)), int(out_len))
+        if r != 0:
+            raise RuntimeError("fxtx_generate: " + self.L.fxrx_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.fxtx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
 def synth_stream(n_samples, stream_id=0, mod=2, fec0=11, fec1=1, check=CRC_24, payload_len=1024, gap=256,
                  snr_db=20.0, cfo=None, phase=None, delay=None, gain=1.0, lead=0, return_payloads=True):
     """One synthetic IQ stream of exactly n_samples samples.

@@ -201,6 +201,32 @@ int fxrx_mod_from_index(int idx);   int fxrx_mod_to_index(unsigned int mod_schem
 int fxrx_inner_from_index(int idx); int fxrx_inner_to_index(unsigned int fec);
 int fxrx_outer_from_index(int idx); int fxrx_outer_to_index(unsigned int fec);
 
+/* ------------------------------------------------------------------------------------------
+ * (3) batched frame generator on the GPU -- the flex_tx counterpart
+ *
+ * What /root/reference/lib/flex_tx_impl.cc:191-209 (send_pkt) does per PDU -- flexframegen_assemble (:200) and
+ * flexframegen_write_samples (:203-205) with the properties of :51-56 / :183-189 -- for many frames in one call,
+ * straight into a device buffer.  Byte work (CRC, FEC, interleaving, bit packing) is done on the host inside the
+ * call; modulation and pulse shaping run on the GPU.  Samples are bit-identical to flexframegen_write_samples.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct fxtx_ctx_s fxtx_ctx;
+typedef struct {
+    flexframegenprops_s props;          /* check, fec0, fec1, mod_scheme of this frame */
+    const unsigned char *header;        /* 14 user bytes, or NULL for zeros */
+    const unsigned char *payload;       /* payload_len bytes (host memory) */
+    unsigned int        payload_len;    /* 0 .. 65535 */
+    float               dt;             /* fractional-sample delay the pulse is designed with (0 = none) */
+    unsigned long long  out_offset;     /* first sample of the frame in the output buffer */
+} fxtx_frame;
+fxtx_ctx    *fxtx_create(int device);                        /* NULL + fxrx_last_error() without a usable GPU */
+void         fxtx_destroy(fxtx_ctx *c);
+unsigned int fxtx_frame_len(const fxtx_frame *f);            /* samples the frame occupies */
+/* Writes every frame's samples to out_device[out_offset ...] (interleaved float32 re,im; out_len samples long).  Frames
+ * must not overlap; samples between frames are left untouched (zero the buffer first).  Returns 0 or FXRX_ERR_*;
+ * synchronous (the frames are in the buffer when the call returns). */
+int          fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, void *out_device,
+                           unsigned long long out_len);
+
 #ifdef __cplusplus
 }
 #endif
