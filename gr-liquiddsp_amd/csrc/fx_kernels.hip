@@ -109,8 +109,11 @@ template <class LDS> __device__ __forceinline__ bool seek_sweep(LDS &L, float x2
         for (int t = 0; t < 8; t++) L.X[kb + 64 * t] = a[t];
     }
     __syncthreads();
-    // CFO sweep: offsets -24..24 dealt round-robin to the waves
-    float bv = -1.0f; uint32_t bk = 0xFFFFFFFFu;
+    // CFO sweep: offsets -24..24 dealt round-robin to the waves.  Only the maximum |R|^2 and the bin it belongs to are
+    // tracked here; the lag of the winner is needed only when the peak clears the threshold, and is then read off one
+    // more transform of the winning bin (same arithmetic, so the value is found again exactly).  Tie rule as before:
+    // first maximum in (bin, lag) order.
+    float bv = -1.0f; uint32_t bo = 0xFFFFFFFFu;
     for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += LDS::WAVES) {
 #pragma unroll
         for (int q = 0; q < 8; q++) {
@@ -119,28 +122,45 @@ template <class LDS> __device__ __forceinline__ bool seek_sweep(LDS &L, float x2
             a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
         }
         fft512_wave(a, L.scr[wave], lane, twA, twB);
-        const uint32_t kb = (uint32_t)(off + FX_RANGE) * FX_NFFT + (lane >> 3) + 8 * (lane & 7);
+        float mo = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);     // |R|^2, R = (a.y, a.x)
 #pragma unroll
-        for (int t = 0; t < 8; t++) {
-            float m = fmaf(a[t].y, a[t].y, a[t].x * a[t].x);  // |R|^2, R = (a.y, a.x)
-            uint32_t k = kb + 64 * t;
-            bool take = (m > bv) || (m == bv && k < bk);
-            bv = take ? m : bv; bk = take ? k : bk;
-        }
+        for (int t = 1; t < 8; t++) mo = fmaxf(mo, fmaf(a[t].y, a[t].y, a[t].x * a[t].x));
+        if (mo > bv) { bv = mo; bo = (uint32_t)(off + FX_RANGE); }          // bins ascend per wave: first maximum kept
     }
-    wave_argmax(bv, bk);
-    if (lane == 0) { L.redv[wave] = bv; L.redk[wave] = bk; }
+    wave_argmax(bv, bo);
+    if (lane == 0) { L.redv[wave] = bv; L.redk[wave] = bo; }
     __syncthreads();
-    bv = L.redv[0]; bk = L.redk[0];
+    bv = L.redv[0]; bo = L.redk[0];
 #pragma unroll
     for (int w = 1; w < LDS::WAVES; w++) {
         float ov = L.redv[w]; uint32_t ok = L.redk[w];
-        bool take = (ov > bv) || (ov == bv && ok < bk);
-        bv = take ? ov : bv; bk = take ? ok : bk;
+        bool take = (ov > bv) || (ov == bv && ok < bo);
+        bv = take ? ov : bv; bo = take ? ok : bo;
     }
     const float g = 1.0f / ((float)FX_NFFT * g0 * sqrtf(s2sum));
     peak = sqrtf(bv) * g;
-    bidx = bk & (FX_NFFT - 1); boff = (int)(bk >> 9) - FX_RANGE;
+    boff = (int)bo - FX_RANGE;
+    if (!(peak > threshold)) return false;
+    // the winner's lag: first lag of bin bo whose |R|^2 equals the maximum
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int i = lane + 64 * q;
+            float2 y = cmulc(L.X[i], L.S[(i - boff) & (FX_NFFT - 1)]);
+            a[q] = make_float2(y.y, y.x);
+        }
+        fft512_wave(a, L.scr[0], lane, twA, twB);
+        uint32_t kmin = 0xFFFFFFFFu;
+        const uint32_t kb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+        for (int t = 7; t >= 0; t--) if (fmaf(a[t].y, a[t].y, a[t].x * a[t].x) == bv) kmin = kb + 64 * t;
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, 64));
+        if (lane == 0) L.redk[0] = kmin;
+    }
+    __syncthreads();
+    bidx = L.redk[0] & (FX_NFFT - 1);
     return (peak > threshold) && (bidx < FX_NFFT - FX_S_LEN);
 }
 
