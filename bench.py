@@ -8,7 +8,10 @@ torch.distributed traffic is the barrier and the max-over-ranks of the elapsed t
 
 A step = reset the synchroniser + one full pass of the stream through the HIP path (walker, payload MF,
 payload PLL, packet decode), decoded payloads copied back to the host, payload symbols left in HBM.
-The IQ is resident in HBM before the timed region starts.
+The IQ is resident in HBM before the timed region starts.  Steps are issued through the library's submit/collect
+pipeline (--depth blocks in flight) and the timed region runs from an idle GPU to an idle GPU, so it contains the
+fill and the drain of that pipeline (about ten block periods): the default K = 200 measures the steady rate, a run
+with --steps 20 reports roughly half of it (profiles/README.md has the numbers).
 
 Prints ONE JSON line on rank 0.
 """
