@@ -144,6 +144,17 @@ struct FxTxJob {
     float    taps[32];      // transmit pulse (29 taps; designed with the frame's fractional delay)
 };
 
+// packet encoder on the GPU (fx_txenc_kernel), one wave per frame; the mirror image of the decoder's front end
+struct FxTxEncJob {
+    uint32_t pay_off;       // payload bytes in the input arena
+    uint32_t n, check, fec0;// payload length, CRC scheme, convolutional (or no) code
+    uint32_t k, l0;         // n + crc_len; bytes after fec0 (fec1 is NONE on this path: l1 == l0)
+    uint32_t perm0_off, perm1_off;   // interleaver gather tables (bit i of the output = bit perm[i] of the input)
+    uint32_t buf_off;       // scratch (two buffers of stride >= l0 + 16)
+    uint32_t idx_off;       // output: payload symbol indices for fx_txgen_kernel
+    uint32_t npay, ms;
+};
+
 // ---- payload stage records ----
 struct FxPayJob {           // one per valid, complete frame
     const float2 *x;        // stream base

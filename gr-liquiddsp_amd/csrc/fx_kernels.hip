@@ -1495,3 +1495,114 @@ extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxT
     hipLaunchKernelGGL(fx_txgen_kernel, dim3(ntiles), dim3(TX_TILE), 0, st, jobs, tile_job, tile_n0, head_syms, pay_idx, sc, out);
     return hipGetLastError();
 }
+
+// ----- packet encoder: CRC, whitening, convolutional code (with puncturing), two interleavers, bit packing, Gray / DPSK
+// index arithmetic -- what fx_codec.hpp::packet_encode + FrameGen::payload_indices do on the host, one wave per frame.
+// Frames with block codes in their chain are encoded on the host (fx_tx.cpp) and skip this kernel.
+__device__ __forceinline__ unsigned tx_gray_dec(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
+
+extern "C" __global__ __launch_bounds__(DEC_THREADS)
+void fx_txenc_kernel(const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx)
+{
+    const FxTxEncJob job = jobs[blockIdx.x];
+    const int lane = threadIdx.x;
+    uint8_t *A = bufA + job.buf_off, *B = bufB + job.buf_off;
+    // message + CRC, whitened
+    for (uint32_t j = lane; j < job.n; j += DEC_THREADS) A[j] = pay[job.pay_off + j];
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    uint32_t key = 0;
+    switch (job.check) {
+    case FX_CRC_CHECKSUM: {
+        uint32_t sm = 0;
+        for (uint32_t j = lane; j < job.n; j += DEC_THREADS) sm += A[j];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sm += (uint32_t)__shfl_xor((int)sm, m, 64);
+        key = (~sm + 1u) & 0xff; break; }
+    case FX_CRC_8:  key = crc_wave(0xE0u, 0xFFu, A, job.n, lane); break;
+    case FX_CRC_16: key = crc_wave(0xA001u, 0xFFFFu, A, job.n, lane); break;
+    case FX_CRC_24: key = crc_wave(0xD3B6BAu, 0xFFFFFFu, A, job.n, lane); break;
+    case FX_CRC_32: key = crc_wave(0xEDB88320u, 0xFFFFFFFFu, A, job.n, lane); break;
+    default: key = 0; break;
+    }
+    const uint32_t cl = job.k - job.n;
+    if ((uint32_t)lane < cl) A[job.n + cl - 1 - lane] = (uint8_t)(key >> (8 * lane));
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    { const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 }; for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3]; }
+    // padding behind the message reads as zero (tail bits of the encoder, slack of the bit windows)
+    if (lane < 8) A[job.k + lane] = 0;
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // fec0: K=7 (0x6d, 0x4f) convolutional code, one output byte per lane and pass
+    const int p = conv_p(job.fec0);
+    if (p) {
+        unsigned pa, pb;
+        switch (p) {
+        case 2: pa = 0x3; pb = 0x1; break;   case 3: pa = 0x3; pb = 0x5; break;   case 4: pa = 0xf; pb = 0x1; break;
+        case 5: pa = 0xb; pb = 0x15; break;  case 6: pa = 0x17; pb = 0x29; break; case 7: pa = 0x2f; pb = 0x51; break;
+        default: pa = 1; pb = 1; break;
+        }
+        // kept bits of one puncturing period, in order: slot r -> (column, generator)
+        unsigned ncol = 0, slot_col[8], slot_gen[8];
+        for (int c = 0; c < p; c++) {
+            if ((pa >> c) & 1) { slot_col[ncol] = (unsigned)c; slot_gen[ncol] = 0x6d; ncol++; }
+            if ((pb >> c) & 1) { slot_col[ncol] = (unsigned)c; slot_gen[ncol] = 0x4f; ncol++; }
+        }
+        const uint32_t Tn = 8 * job.k + 6;
+        const uint32_t nbits = p == 1 ? 2 * Tn : Tn + (Tn + (uint32_t)p - 1) / (uint32_t)p;
+        for (uint32_t j = lane; j < job.l0; j += DEC_THREADS) {
+            unsigned v = 0;
+            for (int b = 0; b < 8; b++) {
+                const uint32_t q = 8 * j + b;
+                unsigned bit = 0;
+                if (q < nbits) {
+                    const uint32_t g = q / ncol, r = q % ncol;
+                    const uint32_t t = g * (uint32_t)p + slot_col[r];
+                    // shift register after step t: input bits t-6 .. t (bit t in the LSB); bits before 0 and past the message are 0
+                    unsigned sr = 0;
+                    for (int i = 6; i >= 0; i--) { const int64_t tt = (int64_t)t - i; sr = (sr << 1) | ((tt >= 0 && tt < (int64_t)(8 * job.k)) ? getbit(A, (uint32_t)tt) : 0u); }
+                    bit = __popc(sr & slot_gen[r]) & 1u;
+                }
+                v = (v << 1) | bit;
+            }
+            B[j] = (uint8_t)v;
+        }
+    } else {
+        for (uint32_t j = lane; j < job.l0; j += DEC_THREADS) B[j] = A[j];
+    }
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    permute_bits(B, A, perm_arena + job.perm0_off, job.l0, lane);               // interleaver of the fec0 stage
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    permute_bits(A, B, perm_arena + job.perm1_off, job.l0, lane);               // fec1 = none: bytes pass, its interleaver runs
+    if (lane < 8) B[job.l0 + lane] = 0;
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // bits -> modem words -> constellation indices (Gray decoding; DPSK: running sum of the decoded words mod M)
+    const unsigned bps = modem_bps(job.ms), M1 = (1u << bps) - 1u;
+    const bool dpsk = job.ms == FX_MODEM_DPSK2 || job.ms == FX_MODEM_DPSK4 || job.ms == FX_MODEM_DPSK8;
+    unsigned carry = 0;
+    for (uint32_t j0 = 0; j0 < job.npay; j0 += DEC_THREADS) {
+        const uint32_t j = j0 + lane;
+        unsigned w = 0;
+        if (j < job.npay) for (unsigned b = 0; b < bps; b++) { const uint32_t q = j * bps + b; w = (w << 1) | (q < 8 * job.l0 ? getbit(B, q) : 0u); }
+        unsigned v;
+        switch (job.ms) {
+        case FX_MODEM_QPSK: v = w; break;
+        case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: case FX_MODEM_ASK4: v = tx_gray_dec(w); break;
+        case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8: v = tx_gray_dec(w); break;
+        default: { const unsigned mq = job.ms == FX_MODEM_QAM64 ? 3u : 2u; v = (tx_gray_dec(w >> mq) << mq) | tx_gray_dec(w & ((1u << mq) - 1u)); }
+        }
+        if (dpsk) {
+            unsigned s_ = v;                                                    // inclusive scan over the 64 symbols of this pass
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { const unsigned o = (unsigned)__shfl_up((int)s_, m, 64); if (lane >= m) s_ += o; }
+            v = (s_ + carry) & M1;
+            carry = (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+        }
+        if (j < job.npay) pay_idx[job.idx_off + j] = (uint8_t)v;
+    }
+}
+
+extern "C" hipError_t fx_launch_txenc(unsigned njobs, hipStream_t st, const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena,
+                                      uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx)
+{
+    hipLaunchKernelGGL(fx_txenc_kernel, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, pay, perm_arena, bufA, bufB, pay_idx);
+    return hipGetLastError();
+}

@@ -2,14 +2,18 @@
 //
 // Replaces, for many frames at once, what /root/reference/lib/flex_tx_impl.cc:191-209 (send_pkt) does per PDU:
 // flexframegen_assemble (:200) + flexframegen_write_samples (:203-205) with the properties set at :51-56 / :183-189.
-// Byte work (CRC, FEC encoders, interleavers, whitening, bit packing, Gray / DPSK index arithmetic) stays on the host
-// (fx_codec.hpp: it is a few kilobytes per frame); modulation and the pulse-shaping interpolator -- all of the float
-// work, 2 x 15 fused multiply-adds per output sample -- run in fx_txgen_kernel, bit-identical to the host generator
-// behind flexframegen_* (fx_dropin.cpp) and to the oracle's fxr_gen_frame.
+// Modulation and the pulse-shaping interpolator -- all of the float work, 2 x 15 fused multiply-adds per output sample
+// -- run in fx_txgen_kernel; the packet encoding (CRC, whitening, convolutional code, interleavers, bit packing, Gray /
+// DPSK index arithmetic) in fx_txenc_kernel, except for frames whose chain contains a block code: those are encoded by
+// fx_codec.hpp on host threads and join at the symbol-index stage.  The 54-byte header packets are always encoded on
+// the host.  Output is bit-identical to the host generator behind flexframegen_* (fx_dropin.cpp) and to the oracle's
+// fxr_gen_frame.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <memory>
 #include <algorithm>
+#include <cstdlib>
+#include <map>
 #include <string>
 #include <thread>
 #include <vector>
@@ -19,6 +23,8 @@
 
 extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0,
                                       const float2 *head_syms, const uint8_t *pay_idx, const float2 *sc, float2 *out);
+extern "C" hipError_t fx_launch_txenc(unsigned njobs, hipStream_t st, const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena,
+                                      uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx);
 extern "C" void fxrx_set_error(const char *msg);       // fx_host.cpp: thread-local message behind fxrx_last_error()
 
 namespace {
@@ -33,6 +39,10 @@ struct fxtx_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
     Dev<float2> d_sc, d_head; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
+    // packet encoder on the GPU: payload bytes, scratch, interleaver gather tables (one per coded length, append-only)
+    Dev<uint8_t> d_pay, d_bufA, d_bufB; Dev<FxTxEncJob> d_ejobs; Dev<uint32_t> d_perm;
+    std::map<uint32_t, uint32_t> perm_off; std::vector<uint32_t> perm_host; size_t perm_uploaded = 0;
+    bool host_encode_only = false;       // FXTX_HOST_ENCODE=1: every frame's packet encoding on the host
 };
 
 extern "C" {
@@ -46,6 +56,7 @@ fxtx_ctx *fxtx_create(int device)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fxrx_set_error("hipStreamCreate failed"); return nullptr; }
     const fx::HostTables &H = fx::host_tables();
+    if (const char *e = std::getenv("FXTX_HOST_ENCODE")) c->host_encode_only = std::atoi(e) != 0;
     if (!c->d_sc.reserve(1024) || hipMemcpy(c->d_sc.p, H.sc, 1024 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) { fxrx_set_error("fxtx_create: table upload failed"); return nullptr; }
     return c.release();
 }
@@ -76,7 +87,8 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
     const fx::HostTables &H = fx::host_tables();
     // pass 1 (serial, cheap): sizes and offsets.  pass 2 (host threads): the byte work of every frame -- CRC, FEC
     // encoders, interleavers, whitening, bit packing, Gray / DPSK index arithmetic -- a few kilobytes each.
-    uint64_t idx_total = 0;
+    uint64_t idx_total = 0, buf_total = 0;
+    std::vector<uint8_t> pay; std::vector<FxTxEncJob> ejobs; std::vector<char> on_gpu(n_frames, 0);
     for (unsigned i = 0; i < n_frames; i++) {
         const fxtx_frame &f = frames[i];
         if (fx::modem_bps(f.props.mod_scheme) == 0 || f.payload_len > 65535u || (!f.payload && f.payload_len)) { fxrx_set_error("fxtx_generate: bad frame description"); return FXRX_ERR_ARG; }
@@ -89,6 +101,26 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
         if (f.out_offset + 2ull * j.nsym > out_len) { fxrx_set_error("fxtx_generate: frame does not fit the output buffer"); return FXRX_ERR_ARG; }
         j.head_off = i * nhead; j.idx_off = (uint32_t)idx_total;
         idx_total += j.npay;
+        // packet encoding on the GPU when the chain is CRC + (convolutional | no) code; block codes are encoded on the host
+        if (!c->host_encode_only && f.props.fec1 == FX_FEC_NONE && (f.props.fec0 == FX_FEC_NONE || fx::conv_period(f.props.fec0) != 0)) {
+            const fx::PacketPlan pl = fx::packet_plan(f.payload_len, f.props.check, f.props.fec0, f.props.fec1);
+            FxTxEncJob e{};
+            e.pay_off = (uint32_t)pay.size(); e.n = f.payload_len; e.check = f.props.check; e.fec0 = f.props.fec0; e.k = pl.k; e.l0 = pl.l0;
+            auto it = c->perm_off.find(pl.l0);
+            if (it == c->perm_off.end()) {
+                // gather table of the interleaver: bit q of the output = bit g[q] of the input (inverse of the de-interleaver's)
+                const std::vector<uint32_t> lab = fx::Interleaver(pl.l0).decode_gather();
+                const uint32_t off = (uint32_t)c->perm_host.size();
+                c->perm_host.resize(off + lab.size());
+                for (size_t q = 0; q < lab.size(); q++) c->perm_host[off + lab[q]] = (uint32_t)q;
+                it = c->perm_off.emplace(pl.l0, off).first;
+            }
+            e.perm0_off = e.perm1_off = it->second;
+            e.buf_off = (uint32_t)buf_total; buf_total += (pl.l0 + 16 + 15) & ~15u;
+            e.idx_off = j.idx_off; e.npay = j.npay; e.ms = j.ms;
+            if (f.payload_len) pay.insert(pay.end(), f.payload, f.payload + f.payload_len);
+            ejobs.push_back(e); on_gpu[i] = 1;
+        }
         for (uint32_t n0 = 0; n0 < j.nsym; n0 += 256) { tile_job.push_back(i); tile_n0.push_back(n0); }
     }
     if (idx_total >= (1ull << 32)) { fxrx_set_error("fxtx_generate: batch too large"); return FXRX_ERR_ARG; }
@@ -100,8 +132,10 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
             fx::FrameGen g; g.ms = f.props.mod_scheme; g.check = f.props.check; g.fec0 = f.props.fec0; g.fec1 = f.props.fec1;
             FxTxJob &j = jobs[i];
             g.head(f.header, f.payload_len, reinterpret_cast<fx::cf *>(head.data() + (size_t)i * nhead));
-            const std::vector<uint8_t> w = g.payload_indices(f.payload, f.payload_len);
-            std::memcpy(idx.data() + j.idx_off, w.data(), w.size());
+            if (!on_gpu[i]) {
+                const std::vector<uint8_t> w = g.payload_indices(f.payload, f.payload_len);
+                std::memcpy(idx.data() + j.idx_off, w.data(), w.size());
+            }
             if (f.dt != 0.0f) fx::design_arkaiser(FX_K, FX_M, FX_BETA, f.dt, j.taps); else std::memcpy(j.taps, H.txh, sizeof H.txh);
         }
     };
@@ -120,6 +154,18 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
     ok = ok && hipMemcpyAsync(c->d_idx.p, idx.data(), idx.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(c->d_tiles.p, tile_job.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(c->d_tiles.p + nt, tile_n0.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (!ejobs.empty()) {
+        pay.resize(pay.size() + 16);
+        if (c->perm_uploaded != c->perm_host.size()) {
+            ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && c->d_perm.reserve(c->perm_host.size()) &&
+                 hipMemcpy(c->d_perm.p, c->perm_host.data(), c->perm_host.size() * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+            c->perm_uploaded = c->perm_host.size();
+        }
+        ok = ok && c->d_pay.reserve(pay.size()) && c->d_bufA.reserve(buf_total + 16) && c->d_bufB.reserve(buf_total + 16) && c->d_ejobs.reserve(ejobs.size());
+        ok = ok && hipMemcpyAsync(c->d_pay.p, pay.data(), pay.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        ok = ok && hipMemcpyAsync(c->d_ejobs.p, ejobs.data(), ejobs.size() * sizeof(FxTxEncJob), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+        ok = ok && fx_launch_txenc((unsigned)ejobs.size(), c->stream, c->d_ejobs.p, c->d_pay.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_idx.p) == hipSuccess;
+    }
     ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_head.p, c->d_idx.p, c->d_sc.p, (float2 *)out_device) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;       // the staging vectors above are pageable and die with this call
     if (!ok) { fxrx_set_error(std::string("fxtx_generate: ") .append(hipGetErrorString(hipGetLastError())).c_str()); return FXRX_ERR_HIP; }

@@ -206,8 +206,9 @@ int fxrx_outer_from_index(int idx); int fxrx_outer_to_index(unsigned int fec);
  *
  * What /root/reference/lib/flex_tx_impl.cc:191-209 (send_pkt) does per PDU -- flexframegen_assemble (:200) and
  * flexframegen_write_samples (:203-205) with the properties of :51-56 / :183-189 -- for many frames in one call,
- * straight into a device buffer.  Byte work (CRC, FEC, interleaving, bit packing) is done on the host inside the
- * call; modulation and pulse shaping run on the GPU.  Samples are bit-identical to flexframegen_write_samples.
+ * straight into a device buffer.  Modulation and pulse shaping run on the GPU; so does the packet encoding (CRC,
+ * whitening, convolutional code, interleavers, bit packing) unless the frame's chain contains a block code, which is
+ * encoded on host threads inside the call.  Samples are bit-identical to flexframegen_write_samples.
  * ------------------------------------------------------------------------------------------ */
 typedef struct fxtx_ctx_s fxtx_ctx;
 typedef struct {

@@ -538,6 +538,21 @@ def test_gpu_frame_generator_bit_exact_and_loopback_on_device(fx, oracle):
         assert np.array_equal(prod.view(np.uint32), ref.view(np.uint32))
         covered[fr["offset"]:fr["offset"] + len(ref)] = True
     assert not np.any(y[~covered])                                 # nothing written outside the frames
+    # the packet encoder on the GPU (chains without block codes): every modulation x {no code, r1/2, punctured 7/8} x CRCs,
+    # empty and odd payload lengths; and the same frames with the encoding forced onto the host
+    enc_frames, off2 = [], 3
+    for i, m in enumerate(mods):
+        for f0 in (1, 11, 20):
+            fr = dict(mod=m, fec0=f0, fec1=1, check=[2, 3, 4, 5, 6][(i + f0) % 5], dt=0.25 if i % 2 else 0.0,
+                      payload=rng.integers(0, 256, [0, 1, 37, 255, 600][(i + f0) % 5], dtype=np.uint8), offset=off2)
+            off2 += tx.frame_len(fr) + 1
+            enc_frames.append(fr)
+    out2 = torch.zeros(off2 + 8, dtype=torch.complex64, device="cuda")
+    tx.generate(enc_frames, out2.data_ptr(), out2.numel())
+    y2 = out2.cpu().numpy()
+    for fr in enc_frames:
+        ref = oracle.gen_frame(fr["payload"], mod=fr["mod"], fec0=fr["fec0"], fec1=fr["fec1"], check=fr["check"], dt=fr["dt"])
+        assert np.array_equal(y2[fr["offset"]:fr["offset"] + len(ref)].view(np.uint32), ref.view(np.uint32)), "GPU-encoded frame (mod %d fec0 %d check %d len %d) differs" % (fr["mod"], fr["fec0"], fr["check"], len(fr["payload"]))
     # loopback on the device: 200 frames, QAM16 r2/3 + PSK4 r1/2 alternating, straight into the receiver
     lb, off = [], 300
     for i in range(200):

@@ -30,5 +30,5 @@ res = rx.results(rx.process_raw([out.data_ptr()], [out.numel()], True))
 ok = sum(1 for g_, fr in zip(res, frames) if g_["payload_valid"] and g_["payload"] == fr["payload"].tobytes())
 print(json.dumps({"frames": len(frames), "samples": off, "gpu_generator_ms_per_call": round(dt * 1e3, 2), "gpu_generator_msamples_per_s": round(off / dt / 1e6, 1),
                   "host_generator_one_core_ms": round(dth * 1e3, 1), "host_generator_msamples_per_s": round(off / dth / 1e6, 1),
-                  "note": "the GPU call includes the host-side packet encoding of all frames and five uploads; clean-channel loopback check",
+                  "note": "the GPU call includes descriptor building, uploads and the packet encoding (on the GPU unless FXTX_HOST_ENCODE=1); clean-channel loopback check",
                   "loopback_frames_ok": ok}))
