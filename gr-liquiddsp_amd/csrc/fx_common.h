@@ -147,12 +147,20 @@ struct FxTxJob {
 // packet encoder on the GPU (fx_txenc_kernel), one wave per frame; the mirror image of the decoder's front end
 struct FxTxEncJob {
     uint32_t pay_off;       // payload bytes in the input arena
-    uint32_t n, check, fec0;// payload length, CRC scheme, convolutional (or no) code
-    uint32_t k, l0;         // n + crc_len; bytes after fec0 (fec1 is NONE on this path: l1 == l0)
+    uint32_t n, check, fec0, fec1;   // payload length, CRC scheme, the two codes of the chain
+    uint32_t k, l0, l1;     // n + crc_len; bytes after fec0; bytes after fec1
     uint32_t perm0_off, perm1_off;   // interleaver gather tables (bit i of the output = bit perm[i] of the input)
-    uint32_t buf_off;       // scratch (two buffers of stride >= l0 + 16)
+    uint32_t buf_off;       // scratch (two buffers of stride >= max(l0, l1) + 16)
     uint32_t idx_off;       // output: payload symbol indices for fx_txgen_kernel
     uint32_t npay, ms;
+};
+// constant tables of the generator kernels
+struct FxTxTables {
+    float2   sc[1024];
+    uint32_t golenc[4096];
+    uint16_t h128enc[256];
+    uint8_t  h74enc[16], h84enc[16], sdcol[64], sd22col[16], sd39col[32];
+    uint8_t  rsexp[512], rslog[256], rsgen[40];
 };
 
 // ---- payload stage records ----

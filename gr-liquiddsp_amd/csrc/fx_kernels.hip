@@ -1496,20 +1496,113 @@ extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxT
     return hipGetLastError();
 }
 
-// ----- packet encoder: CRC, whitening, convolutional code (with puncturing), two interleavers, bit packing, Gray / DPSK
-// index arithmetic -- what fx_codec.hpp::packet_encode + FrameGen::payload_indices do on the host, one wave per frame.
-// Frames with block codes in their chain are encoded on the host (fx_tx.cpp) and skip this kernel.
+// ----- packet encoder: CRC, whitening, two code stages (convolutional with puncturing, Hamming, Golay, SECDED,
+// Reed-Solomon), two interleavers, bit packing, Gray / DPSK index arithmetic -- what fx_codec.hpp::packet_encode +
+// FrameGen::payload_indices do on the host, one wave per frame.
 __device__ __forceinline__ unsigned tx_gray_dec(unsigned x) { unsigned y = x; while (x >>= 1) y ^= x; return y; }
 
+// one code stage: n bytes at src -> fec_enc_len(fs, n) bytes at dst (src has >= 8 zero bytes of slack behind it)
+__device__ __forceinline__ void tx_fec_encode(unsigned fs, uint32_t n, const uint8_t *src, uint8_t *dst, int lane, const FxTxTables *T)
+{
+    const uint32_t el = fec_enc_len(fs, n);
+    const int p = conv_p(fs);
+    unsigned bk, bn;
+    if (p) {                                     // K=7 (0x6d, 0x4f): every coded bit is a parity of a 7-bit window; a byte per lane
+        unsigned pa, pb;
+        switch (p) {
+        case 2: pa = 0x3; pb = 0x1; break;   case 3: pa = 0x3; pb = 0x5; break;   case 4: pa = 0xf; pb = 0x1; break;
+        case 5: pa = 0xb; pb = 0x15; break;  case 6: pa = 0x17; pb = 0x29; break; case 7: pa = 0x2f; pb = 0x51; break;
+        default: pa = 1; pb = 1; break;
+        }
+        unsigned ncol = 0, slot_col[8], slot_gen[8];        // kept bits of one puncturing period: slot -> (column, generator)
+        for (int c = 0; c < p; c++) {
+            if ((pa >> c) & 1) { slot_col[ncol] = (unsigned)c; slot_gen[ncol] = 0x6d; ncol++; }
+            if ((pb >> c) & 1) { slot_col[ncol] = (unsigned)c; slot_gen[ncol] = 0x4f; ncol++; }
+        }
+        const uint32_t Tn = 8 * n + 6;
+        const uint32_t nbits = p == 1 ? 2 * Tn : Tn + (Tn + (uint32_t)p - 1) / (uint32_t)p;
+        for (uint32_t j = lane; j < el; j += DEC_THREADS) {
+            unsigned v = 0;
+            for (int b = 0; b < 8; b++) {
+                const uint32_t q = 8 * j + b;
+                unsigned bit = 0;
+                if (q < nbits) {
+                    const uint32_t g = q / ncol, r = q % ncol;
+                    const uint32_t t = g * (uint32_t)p + slot_col[r];
+                    unsigned sr = 0;                        // input bits t-6 .. t, bit t in the LSB; outside the message: 0
+                    for (int i = 6; i >= 0; i--) { const int64_t tt = (int64_t)t - i; sr = (sr << 1) | ((tt >= 0 && tt < (int64_t)(8 * n)) ? getbit(src, (uint32_t)tt) : 0u); }
+                    bit = __popc(sr & slot_gen[r]) & 1u;
+                }
+                v = (v << 1) | bit;
+            }
+            dst[j] = (uint8_t)v;
+        }
+    } else if (blk_spec(fs, bk, bn)) {           // bit-packed block codes: k-bit blocks -> n-bit codewords back to back
+        const uint32_t nb = (8 * n + bk - 1) / bk;
+        for (uint32_t j = lane; j < el; j += DEC_THREADS) {
+            unsigned v = 0;
+            for (int b = 0; b < 8; b++) {
+                const uint32_t q = 8 * j + b, cwi = q / bn, pos = q % bn;
+                unsigned bit = 0;
+                if (cwi < nb) {
+                    unsigned d = 0;
+                    for (unsigned i = 0; i < bk; i++) { const uint32_t qq = cwi * bk + i; d = (d << 1) | (qq < 8 * n ? getbit(src, qq) : 0u); }
+                    const uint32_t cw = fs == FX_FEC_HAMMING74 ? T->h74enc[d] : (fs == FX_FEC_HAMMING128 ? T->h128enc[d] : T->golenc[d]);
+                    bit = (cw >> (bn - 1 - pos)) & 1u;
+                }
+                v = (v << 1) | bit;
+            }
+            dst[j] = (uint8_t)v;
+        }
+    } else if (fs == FX_FEC_HAMMING84) {
+        for (uint32_t i = lane; i < n; i += DEC_THREADS) { dst[2 * i] = T->h84enc[src[i] >> 4]; dst[2 * i + 1] = T->h84enc[src[i] & 15]; }
+    } else if (fs == FX_FEC_SECDED7264 || fs == FX_FEC_SECDED2216 || fs == FX_FEC_SECDED3932) {
+        const uint32_t nd = fs == FX_FEC_SECDED7264 ? 8u : (fs == FX_FEC_SECDED2216 ? 2u : 4u);
+        const uint8_t *col = fs == FX_FEC_SECDED7264 ? T->sdcol : (fs == FX_FEC_SECDED2216 ? T->sd22col : T->sd39col);
+        const uint32_t nblk = (n + nd - 1) / nd;
+        for (uint32_t blk = lane; blk < nblk; blk += DEC_THREADS) {
+            const uint32_t nbytes = min(nd, n - nd * blk);
+            uint8_t par = 0;
+            for (uint32_t j = 0; j < 8 * nbytes; j++) if (src[nd * blk + (j >> 3)] & (0x80u >> (j & 7))) par ^= col[j];
+            dst[(nd + 1) * blk] = par;
+            for (uint32_t j = 0; j < nbytes; j++) dst[(nd + 1) * blk + 1 + j] = src[nd * blk + j];
+        }
+    } else if (fs == FX_FEC_RS_M8) {             // RS(255,223): equal shortened blocks, a lane per block
+        const uint32_t nb = max(1u, (n + 222u) / 223u), dl = (n + nb - 1) / nb;
+        for (uint32_t b = lane; b < nb; b += DEC_THREADS) {
+            uint8_t par[32];
+#pragma unroll
+            for (int k = 0; k < 32; k++) par[k] = 0;
+            const uint32_t off = b * dl, len = off < n ? min(n - off, dl) : 0u;
+            uint8_t *o = dst + b * (dl + 32);
+            for (uint32_t i = 0; i < dl; i++) {
+                const uint8_t di = i < len ? src[off + i] : (uint8_t)0;
+                o[i] = di;
+                const uint8_t fb = (uint8_t)(di ^ par[31]);
+                const unsigned lf = T->rslog[fb];
+#pragma unroll
+                for (int k = 31; k > 0; k--) par[k] = (uint8_t)(par[k - 1] ^ ((fb && T->rsgen[k]) ? T->rsexp[lf + T->rslog[T->rsgen[k]]] : 0));
+                par[0] = (fb && T->rsgen[0]) ? T->rsexp[lf + T->rslog[T->rsgen[0]]] : (uint8_t)0;
+            }
+#pragma unroll
+            for (int k = 0; k < 32; k++) o[dl + k] = par[31 - k];
+        }
+    } else {
+        for (uint32_t j = lane; j < n; j += DEC_THREADS) dst[j] = src[j];
+    }
+}
+
 extern "C" __global__ __launch_bounds__(DEC_THREADS)
-void fx_txenc_kernel(const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx)
+void fx_txenc_kernel(const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx,
+                     const FxTxTables *T)
 {
     const FxTxEncJob job = jobs[blockIdx.x];
     const int lane = threadIdx.x;
     uint8_t *A = bufA + job.buf_off, *B = bufB + job.buf_off;
+    auto sync = [&]() { __threadfence_block(); __builtin_amdgcn_wave_barrier(); };
     // message + CRC, whitened
     for (uint32_t j = lane; j < job.n; j += DEC_THREADS) A[j] = pay[job.pay_off + j];
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    sync();
     uint32_t key = 0;
     switch (job.check) {
     case FX_CRC_CHECKSUM: {
@@ -1526,54 +1619,20 @@ void fx_txenc_kernel(const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t 
     }
     const uint32_t cl = job.k - job.n;
     if ((uint32_t)lane < cl) A[job.n + cl - 1 - lane] = (uint8_t)(key >> (8 * lane));
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    sync();
     { const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 }; for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3]; }
-    // padding behind the message reads as zero (tail bits of the encoder, slack of the bit windows)
-    if (lane < 8) A[job.k + lane] = 0;
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    // fec0: K=7 (0x6d, 0x4f) convolutional code, one output byte per lane and pass
-    const int p = conv_p(job.fec0);
-    if (p) {
-        unsigned pa, pb;
-        switch (p) {
-        case 2: pa = 0x3; pb = 0x1; break;   case 3: pa = 0x3; pb = 0x5; break;   case 4: pa = 0xf; pb = 0x1; break;
-        case 5: pa = 0xb; pb = 0x15; break;  case 6: pa = 0x17; pb = 0x29; break; case 7: pa = 0x2f; pb = 0x51; break;
-        default: pa = 1; pb = 1; break;
-        }
-        // kept bits of one puncturing period, in order: slot r -> (column, generator)
-        unsigned ncol = 0, slot_col[8], slot_gen[8];
-        for (int c = 0; c < p; c++) {
-            if ((pa >> c) & 1) { slot_col[ncol] = (unsigned)c; slot_gen[ncol] = 0x6d; ncol++; }
-            if ((pb >> c) & 1) { slot_col[ncol] = (unsigned)c; slot_gen[ncol] = 0x4f; ncol++; }
-        }
-        const uint32_t Tn = 8 * job.k + 6;
-        const uint32_t nbits = p == 1 ? 2 * Tn : Tn + (Tn + (uint32_t)p - 1) / (uint32_t)p;
-        for (uint32_t j = lane; j < job.l0; j += DEC_THREADS) {
-            unsigned v = 0;
-            for (int b = 0; b < 8; b++) {
-                const uint32_t q = 8 * j + b;
-                unsigned bit = 0;
-                if (q < nbits) {
-                    const uint32_t g = q / ncol, r = q % ncol;
-                    const uint32_t t = g * (uint32_t)p + slot_col[r];
-                    // shift register after step t: input bits t-6 .. t (bit t in the LSB); bits before 0 and past the message are 0
-                    unsigned sr = 0;
-                    for (int i = 6; i >= 0; i--) { const int64_t tt = (int64_t)t - i; sr = (sr << 1) | ((tt >= 0 && tt < (int64_t)(8 * job.k)) ? getbit(A, (uint32_t)tt) : 0u); }
-                    bit = __popc(sr & slot_gen[r]) & 1u;
-                }
-                v = (v << 1) | bit;
-            }
-            B[j] = (uint8_t)v;
-        }
-    } else {
-        for (uint32_t j = lane; j < job.l0; j += DEC_THREADS) B[j] = A[j];
-    }
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    permute_bits(B, A, perm_arena + job.perm0_off, job.l0, lane);               // interleaver of the fec0 stage
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    permute_bits(A, B, perm_arena + job.perm1_off, job.l0, lane);               // fec1 = none: bytes pass, its interleaver runs
-    if (lane < 8) B[job.l0 + lane] = 0;
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    if (lane < 8) A[job.k + lane] = 0;                                          // slack behind the message reads as zero
+    sync();
+    tx_fec_encode(job.fec0, job.k, A, B, lane, T);
+    sync();
+    permute_bits(B, A, perm_arena + job.perm0_off, job.l0, lane);               // interleaver of the first stage
+    if (lane < 8) A[job.l0 + lane] = 0;
+    sync();
+    tx_fec_encode(job.fec1, job.l0, A, B, lane, T);
+    sync();
+    permute_bits(B, A, perm_arena + job.perm1_off, job.l1, lane);               // interleaver of the second stage
+    if (lane < 8) A[job.l1 + lane] = 0;
+    sync();
     // bits -> modem words -> constellation indices (Gray decoding; DPSK: running sum of the decoded words mod M)
     const unsigned bps = modem_bps(job.ms), M1 = (1u << bps) - 1u;
     const bool dpsk = job.ms == FX_MODEM_DPSK2 || job.ms == FX_MODEM_DPSK4 || job.ms == FX_MODEM_DPSK8;
@@ -1581,11 +1640,11 @@ void fx_txenc_kernel(const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t 
     for (uint32_t j0 = 0; j0 < job.npay; j0 += DEC_THREADS) {
         const uint32_t j = j0 + lane;
         unsigned w = 0;
-        if (j < job.npay) for (unsigned b = 0; b < bps; b++) { const uint32_t q = j * bps + b; w = (w << 1) | (q < 8 * job.l0 ? getbit(B, q) : 0u); }
+        if (j < job.npay) for (unsigned b = 0; b < bps; b++) { const uint32_t q = j * bps + b; w = (w << 1) | (q < 8 * job.l1 ? getbit(A, q) : 0u); }
         unsigned v;
         switch (job.ms) {
         case FX_MODEM_QPSK: v = w; break;
-        case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: case FX_MODEM_ASK4: v = tx_gray_dec(w); break;
+        case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: case FX_MODEM_ASK4:
         case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8: v = tx_gray_dec(w); break;
         default: { const unsigned mq = job.ms == FX_MODEM_QAM64 ? 3u : 2u; v = (tx_gray_dec(w >> mq) << mq) | tx_gray_dec(w & ((1u << mq) - 1u)); }
         }
@@ -1601,8 +1660,8 @@ void fx_txenc_kernel(const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t 
 }
 
 extern "C" hipError_t fx_launch_txenc(unsigned njobs, hipStream_t st, const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena,
-                                      uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx)
+                                      uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx, const FxTxTables *T)
 {
-    hipLaunchKernelGGL(fx_txenc_kernel, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, pay, perm_arena, bufA, bufB, pay_idx);
+    hipLaunchKernelGGL(fx_txenc_kernel, dim3(njobs), dim3(DEC_THREADS), 0, st, jobs, pay, perm_arena, bufA, bufB, pay_idx, T);
     return hipGetLastError();
 }

@@ -3,10 +3,9 @@
 // Replaces, for many frames at once, what /root/reference/lib/flex_tx_impl.cc:191-209 (send_pkt) does per PDU:
 // flexframegen_assemble (:200) + flexframegen_write_samples (:203-205) with the properties set at :51-56 / :183-189.
 // Modulation and the pulse-shaping interpolator -- all of the float work, 2 x 15 fused multiply-adds per output sample
-// -- run in fx_txgen_kernel; the packet encoding (CRC, whitening, convolutional code, interleavers, bit packing, Gray /
-// DPSK index arithmetic) in fx_txenc_kernel, except for frames whose chain contains a block code: those are encoded by
-// fx_codec.hpp on host threads and join at the symbol-index stage.  The 54-byte header packets are always encoded on
-// the host.  Output is bit-identical to the host generator behind flexframegen_* (fx_dropin.cpp) and to the oracle's
+// -- run in fx_txgen_kernel; the packet encoding (CRC, whitening, both code stages, interleavers, bit packing, Gray /
+// DPSK index arithmetic) in fx_txenc_kernel.  The 54-byte header packets are encoded on the host (fx_codec.hpp), and so
+// are the payload packets when FXTX_HOST_ENCODE=1 (host threads; they join at the symbol-index stage).  Output is bit-identical to the host generator behind flexframegen_* (fx_dropin.cpp) and to the oracle's
 // fxr_gen_frame.
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -24,7 +23,7 @@
 extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0,
                                       const float2 *head_syms, const uint8_t *pay_idx, const float2 *sc, float2 *out);
 extern "C" hipError_t fx_launch_txenc(unsigned njobs, hipStream_t st, const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena,
-                                      uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx);
+                                      uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx, const FxTxTables *T);
 extern "C" void fxrx_set_error(const char *msg);       // fx_host.cpp: thread-local message behind fxrx_last_error()
 
 namespace {
@@ -38,7 +37,7 @@ template <class T> struct Dev {
 struct fxtx_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
-    Dev<float2> d_sc, d_head; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
+    Dev<FxTxTables> d_tab; Dev<float2> d_head; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
     // packet encoder on the GPU: payload bytes, scratch, interleaver gather tables (one per coded length, append-only)
     Dev<uint8_t> d_pay, d_bufA, d_bufB; Dev<FxTxEncJob> d_ejobs; Dev<uint32_t> d_perm;
     std::map<uint32_t, uint32_t> perm_off; std::vector<uint32_t> perm_host; size_t perm_uploaded = 0;
@@ -56,8 +55,16 @@ fxtx_ctx *fxtx_create(int device)
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { fxrx_set_error("hipStreamCreate failed"); return nullptr; }
     const fx::HostTables &H = fx::host_tables();
+    const fx::BlockCodes &B = fx::block_codes();
     if (const char *e = std::getenv("FXTX_HOST_ENCODE")) c->host_encode_only = std::atoi(e) != 0;
-    if (!c->d_sc.reserve(1024) || hipMemcpy(c->d_sc.p, H.sc, 1024 * sizeof(float2), hipMemcpyHostToDevice) != hipSuccess) { fxrx_set_error("fxtx_create: table upload failed"); return nullptr; }
+    std::unique_ptr<FxTxTables> t(new FxTxTables);
+    std::memset(t.get(), 0, sizeof(FxTxTables));
+    for (int i = 0; i < 1024; i++) t->sc[i] = make_float2(H.sc[i].re, H.sc[i].im);
+    std::memcpy(t->golenc, B.gol_enc, sizeof t->golenc); std::memcpy(t->h128enc, B.h128_enc, sizeof t->h128enc);
+    std::memcpy(t->h74enc, B.h74_enc, 16); std::memcpy(t->h84enc, B.h84_enc, 16);
+    std::memcpy(t->sdcol, B.sd_col, 64); std::memcpy(t->sd22col, B.sd22_col, 16); std::memcpy(t->sd39col, B.sd39_col, 32);
+    std::memcpy(t->rsexp, B.rs_exp, 512); std::memcpy(t->rslog, B.rs_log, 256); std::memcpy(t->rsgen, B.rs_gen, 33);
+    if (!c->d_tab.reserve(1) || hipMemcpy(c->d_tab.p, t.get(), sizeof(FxTxTables), hipMemcpyHostToDevice) != hipSuccess) { fxrx_set_error("fxtx_create: table upload failed"); return nullptr; }
     return c.release();
 }
 
@@ -101,22 +108,26 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
         if (f.out_offset + 2ull * j.nsym > out_len) { fxrx_set_error("fxtx_generate: frame does not fit the output buffer"); return FXRX_ERR_ARG; }
         j.head_off = i * nhead; j.idx_off = (uint32_t)idx_total;
         idx_total += j.npay;
-        // packet encoding on the GPU when the chain is CRC + (convolutional | no) code; block codes are encoded on the host
-        if (!c->host_encode_only && f.props.fec1 == FX_FEC_NONE && (f.props.fec0 == FX_FEC_NONE || fx::conv_period(f.props.fec0) != 0)) {
+        // packet encoding on the GPU (fx_txenc_kernel) unless forced onto the host
+        if (!c->host_encode_only && fx::fec_supported(f.props.fec0) && fx::fec_supported(f.props.fec1)) {
             const fx::PacketPlan pl = fx::packet_plan(f.payload_len, f.props.check, f.props.fec0, f.props.fec1);
             FxTxEncJob e{};
-            e.pay_off = (uint32_t)pay.size(); e.n = f.payload_len; e.check = f.props.check; e.fec0 = f.props.fec0; e.k = pl.k; e.l0 = pl.l0;
-            auto it = c->perm_off.find(pl.l0);
-            if (it == c->perm_off.end()) {
-                // gather table of the interleaver: bit q of the output = bit g[q] of the input (inverse of the de-interleaver's)
-                const std::vector<uint32_t> lab = fx::Interleaver(pl.l0).decode_gather();
-                const uint32_t off = (uint32_t)c->perm_host.size();
-                c->perm_host.resize(off + lab.size());
-                for (size_t q = 0; q < lab.size(); q++) c->perm_host[off + lab[q]] = (uint32_t)q;
-                it = c->perm_off.emplace(pl.l0, off).first;
-            }
-            e.perm0_off = e.perm1_off = it->second;
-            e.buf_off = (uint32_t)buf_total; buf_total += (pl.l0 + 16 + 15) & ~15u;
+            e.pay_off = (uint32_t)pay.size(); e.n = f.payload_len; e.check = f.props.check; e.fec0 = f.props.fec0; e.fec1 = f.props.fec1;
+            e.k = pl.k; e.l0 = pl.l0; e.l1 = pl.l1;
+            auto perm_for = [&](uint32_t len) -> uint32_t {
+                auto it = c->perm_off.find(len);
+                if (it == c->perm_off.end()) {
+                    // gather table of the interleaver: bit q of the output = bit g[q] of the input (inverse of the de-interleaver's)
+                    const std::vector<uint32_t> lab = fx::Interleaver(len).decode_gather();
+                    const uint32_t off = (uint32_t)c->perm_host.size();
+                    c->perm_host.resize(off + lab.size());
+                    for (size_t q = 0; q < lab.size(); q++) c->perm_host[off + lab[q]] = (uint32_t)q;
+                    it = c->perm_off.emplace(len, off).first;
+                }
+                return it->second;
+            };
+            e.perm0_off = perm_for(pl.l0); e.perm1_off = perm_for(pl.l1);
+            e.buf_off = (uint32_t)buf_total; buf_total += (std::max(pl.l0, pl.l1) + 16 + 15) & ~15u;
             e.idx_off = j.idx_off; e.npay = j.npay; e.ms = j.ms;
             if (f.payload_len) pay.insert(pay.end(), f.payload, f.payload + f.payload_len);
             ejobs.push_back(e); on_gpu[i] = 1;
@@ -164,9 +175,9 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
         ok = ok && c->d_pay.reserve(pay.size()) && c->d_bufA.reserve(buf_total + 16) && c->d_bufB.reserve(buf_total + 16) && c->d_ejobs.reserve(ejobs.size());
         ok = ok && hipMemcpyAsync(c->d_pay.p, pay.data(), pay.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess;
         ok = ok && hipMemcpyAsync(c->d_ejobs.p, ejobs.data(), ejobs.size() * sizeof(FxTxEncJob), hipMemcpyHostToDevice, c->stream) == hipSuccess;
-        ok = ok && fx_launch_txenc((unsigned)ejobs.size(), c->stream, c->d_ejobs.p, c->d_pay.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_idx.p) == hipSuccess;
+        ok = ok && fx_launch_txenc((unsigned)ejobs.size(), c->stream, c->d_ejobs.p, c->d_pay.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_idx.p, c->d_tab.p) == hipSuccess;
     }
-    ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_head.p, c->d_idx.p, c->d_sc.p, (float2 *)out_device) == hipSuccess;
+    ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_head.p, c->d_idx.p, reinterpret_cast<const float2 *>(c->d_tab.p) /* FxTxTables::sc is its first member */, (float2 *)out_device) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;       // the staging vectors above are pageable and die with this call
     if (!ok) { fxrx_set_error(std::string("fxtx_generate: ") .append(hipGetErrorString(hipGetLastError())).c_str()); return FXRX_ERR_HIP; }
     return 0;

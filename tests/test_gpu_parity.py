@@ -553,6 +553,12 @@ def test_gpu_frame_generator_bit_exact_and_loopback_on_device(fx, oracle):
     for fr in enc_frames:
         ref = oracle.gen_frame(fr["payload"], mod=fr["mod"], fec0=fr["fec0"], fec1=fr["fec1"], check=fr["check"], dt=fr["dt"])
         assert np.array_equal(y2[fr["offset"]:fr["offset"] + len(ref)].view(np.uint32), ref.view(np.uint32)), "GPU-encoded frame (mod %d fec0 %d check %d len %d) differs" % (fr["mod"], fr["fec0"], fr["check"], len(fr["payload"]))
+    # maximum payload length through the GPU encoder (Reed-Solomon + punctured convolutional code, 0.5 M symbols)
+    bigfr = dict(mod=29, fec0=17, fec1=27, check=6, payload=rng.integers(0, 256, 65535, dtype=np.uint8), dt=-0.3, offset=5)
+    outb = torch.zeros(tx.frame_len(bigfr) + 16, dtype=torch.complex64, device="cuda")
+    tx.generate([bigfr], outb.data_ptr(), outb.numel())
+    refb = oracle.gen_frame(bigfr["payload"], mod=29, fec0=17, fec1=27, check=6, dt=-0.3)
+    assert np.array_equal(outb.cpu().numpy()[5:5 + len(refb)].view(np.uint32), refb.view(np.uint32))
     # loopback on the device: 200 frames, QAM16 r2/3 + PSK4 r1/2 alternating, straight into the receiver
     lb, off = [], 300
     for i in range(200):
