@@ -575,3 +575,38 @@ def test_gpu_frame_generator_bit_exact_and_loopback_on_device(fx, oracle):
     with pytest.raises(RuntimeError):
         tx.generate([dict(payload=np.zeros(10, np.uint8), offset=sig.numel() - 5)], sig.data_ptr(), sig.numel())   # does not fit
     tx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode,depth", [("independent", 5), ("continuous", 4), ("reset-every-3", 7)])
+def test_pipeline_soak_every_block_checked(fx, mode, depth):
+    """120 blocks through submit/collect, every block's results compared: the first 24 with the same calls made one block
+    at a time (the serial host path), the rest with the block one period earlier (the capture repeats).  Catches the
+    races a handful of blocks would not: stream / event / buffer reuse across slots and walk streams."""
+    import torch
+    x = fx.synth_stream(1_200_000, stream_id=91, payload_len=256)[0]
+    xd = torch.from_numpy(x).cuda()
+    ptrs, counts = [xd.data_ptr()], [xd.numel()]
+    key = lambda g: (g["start"], g["payload_valid"], hash(g["payload"]), g["evm_sum"], g["rxy"])
+    resets = lambda b: mode == "independent" or (mode == "reset-every-3" and b % 3 == 0)
+    per = 3 if mode == "reset-every-3" else 1
+    ref_ctx, refs = fx.RxContext(1), []
+    for b in range(24):
+        if resets(b): ref_ctx.reset()
+        refs.append([key(g) for g in ref_ctx.results(ref_ctx.process_raw(ptrs, counts, True))])
+    assert len(refs[0]) > 150
+    ctx = fx.RxContext(1); ctx.set_depth(depth)
+    got, inflight = [], 0
+    def collect():
+        g = [key(r) for r in ctx.results(ctx.collect_raw())]
+        b = len(got)
+        if b < 24: want = refs[b]
+        else: want = [(k[0] + (len(x) * per if mode == "continuous" else 0),) + k[1:] for k in got[b - per]]
+        assert g == want, "%s: block %d differs" % (mode, b)
+        got.append(g)
+    for b in range(120):
+        if inflight == depth: collect(); inflight -= 1
+        if resets(b): ctx.reset()
+        ctx.submit_raw(ptrs, counts, True); inflight += 1
+    while inflight: collect(); inflight -= 1
+    assert len(got) == 120
