@@ -509,18 +509,28 @@ struct FrameGen {
         return bps ? (8 * p.l1 + bps - 1) / bps : 0;
     }
     unsigned frame_len(unsigned payload_len) const { return FX_K * (FX_PN_LEN + FX_HDR_SYM + payload_syms(payload_len) + 2 * FX_M); }
+    // the 20 header bytes: 14 user bytes + protocol id, payload length, modulation, CRC / FEC schemes
+    void head_bytes(const uint8_t *header14, unsigned payload_len, uint8_t *hd) const
+    {
+        if (header14) std::memcpy(hd, header14, FX_HDR_USER); else std::memset(hd, 0, FX_HDR_USER);
+        hd[14] = FX_PROTOCOL; hd[15] = (uint8_t)((payload_len >> 8) & 0xff); hd[16] = (uint8_t)(payload_len & 0xff);
+        hd[17] = (uint8_t)ms; hd[18] = (uint8_t)(((check & 7) << 5) | (fec0 & 0x1f)); hd[19] = (uint8_t)(fec1 & 0x1f);
+    }
+    // ... encoded (CRC-32, SECDED(72,64), Hamming(8,4)) and cut into the 216 QPSK words of the header symbols
+    void head_words(const uint8_t *header14, unsigned payload_len, uint8_t *hs) const
+    {
+        uint8_t hd[FX_HDR_DEC];
+        head_bytes(header14, payload_len, hd);
+        PacketPlan hp = packet_plan(FX_HDR_DEC, FX_CRC_32, FX_FEC_SECDED7264, FX_FEC_HAMMING84);
+        std::vector<uint8_t> he = packet_encode(hp, hd);
+        pack_symbols(he.data(), FX_HDR_ENC, 2, FX_HDR_MOD, hs);
+    }
     // preamble + header symbols (FX_PN_LEN + FX_HDR_SYM of them)
     void head(const uint8_t *header14, unsigned payload_len, cf *out) const
     {
         const HostTables &T = host_tables();
         std::memcpy(out, T.pn, sizeof T.pn);
-        uint8_t hd[FX_HDR_DEC];
-        if (header14) std::memcpy(hd, header14, FX_HDR_USER); else std::memset(hd, 0, FX_HDR_USER);
-        hd[14] = FX_PROTOCOL; hd[15] = (uint8_t)((payload_len >> 8) & 0xff); hd[16] = (uint8_t)(payload_len & 0xff);
-        hd[17] = (uint8_t)ms; hd[18] = (uint8_t)(((check & 7) << 5) | (fec0 & 0x1f)); hd[19] = (uint8_t)(fec1 & 0x1f);
-        PacketPlan hp = packet_plan(FX_HDR_DEC, FX_CRC_32, FX_FEC_SECDED7264, FX_FEC_HAMMING84);
-        std::vector<uint8_t> he = packet_encode(hp, hd);
-        uint8_t hs[FX_HDR_MOD]; pack_symbols(he.data(), FX_HDR_ENC, 2, FX_HDR_MOD, hs);
+        uint8_t hs[FX_HDR_MOD]; head_words(header14, payload_len, hs);
         Modulator qm(FX_MODEM_QPSK, T.sc);
         for (unsigned i = 0, n = 0, pp = 0; i < FX_HDR_SYM; i++)
             out[FX_PN_LEN + i] = (i % FX_PILOT_SPACING) == 0 ? T.pilots[pp++] : qm.mod(hs[n++]);

@@ -138,7 +138,7 @@ struct FxTxJob {
     uint32_t nsym;          // symbols incl. the 2m flush zeros (output = 2 nsym samples)
     uint32_t npay;          // payload symbols
     uint32_t ms;            // payload modulation
-    uint32_t head_off;      // offset of the frame's 295 ready-made preamble + header symbols
+    uint32_t head_off;      // offset of the frame's 216 header symbol indices (QPSK words), one byte each
     uint32_t idx_off;       // offset of its payload symbol indices (one byte each)
     uint32_t pad_;
     float    taps[32];      // transmit pulse (29 taps; designed with the frame's fractional delay)
@@ -161,6 +161,7 @@ struct FxTxTables {
     uint16_t h128enc[256];
     uint8_t  h74enc[16], h84enc[16], sdcol[64], sd22col[16], sd39col[32];
     uint8_t  rsexp[512], rslog[256], rsgen[40];
+    float2   pn[FX_PN_LEN], pilots[16];
 };
 
 // ---- payload stage records ----

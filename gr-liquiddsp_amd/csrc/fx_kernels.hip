@@ -1421,9 +1421,9 @@ extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, unsigned wav
 }
 
 // ===================================================================== frame generator (flex_tx counterpart)
-// One thread per symbol n of a frame: constellation point of the symbol (preamble / header symbols come ready-made
-// from the host, payload symbols as indices -- the bit packing, and for DPSK the running phase index, are byte work
-// done while the packet is encoded), then the two output samples y[2n+i] = sum_t h[i+2t] x[n-t], t ascending,
+// One thread per symbol n of a frame: constellation point of the symbol (preamble from the table, header = pilots +
+// QPSK of the encoded header packet, payload from its symbol indices -- the indices come from fx_txenc_kernel), then
+// the two output samples y[2n+i] = sum_t h[i+2t] x[n-t], t ascending,
 // exactly as the host generator and the oracle accumulate them.  Symbols are staged through LDS (256 + 14 per tile).
 #define TX_TILE 256
 __device__ __forceinline__ float2 tx_point(unsigned ms, unsigned v, const float2 *sc)
@@ -1451,9 +1451,10 @@ __device__ __forceinline__ float2 tx_point(unsigned ms, unsigned v, const float2
 }
 
 extern "C" __global__ __launch_bounds__(TX_TILE)
-void fx_txgen_kernel(const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0, const float2 *head_syms, const uint8_t *pay_idx,
-                     const float2 *sc, float2 *out)
+void fx_txgen_kernel(const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0, const uint8_t *head_idx, const uint8_t *pay_idx,
+                     const FxTxTables *T, float2 *out)
 {
+    const float2 *sc = T->sc;
     __shared__ float2 xs[TX_TILE + 14];
     __shared__ float h[32];
     const FxTxJob job = jobs[tile_job[blockIdx.x]];
@@ -1464,7 +1465,12 @@ void fx_txgen_kernel(const FxTxJob *jobs, const uint32_t *tile_job, const uint32
     for (int i = tid; i < TX_TILE + 14; i += TX_TILE) {
         const int64_t n = (int64_t)n0 - 14 + i;
         float2 v = make_float2(0.0f, 0.0f);
-        if (n >= 0 && n < (int64_t)nhead) v = head_syms[(size_t)job.head_off + (size_t)n];
+        if (n >= 0 && n < (int64_t)FX_PN_LEN) v = T->pn[n];
+        else if (n >= (int64_t)FX_PN_LEN && n < (int64_t)nhead) {                // header: a pilot every 16th symbol, QPSK in between
+            const uint32_t hi = (uint32_t)n - FX_PN_LEN;
+            if (hi % FX_PILOT_SPACING == 0) v = T->pilots[hi / FX_PILOT_SPACING];
+            else v = tx_point(FX_MODEM_QPSK, head_idx[(size_t)job.head_off + hi - 1u - hi / FX_PILOT_SPACING], sc);
+        }
         else if (n >= (int64_t)nhead && n < (int64_t)(nhead + job.npay)) v = tx_point(job.ms, pay_idx[(size_t)job.idx_off + (size_t)(n - nhead)], sc);
         xs[i] = v;
     }
@@ -1490,9 +1496,9 @@ void fx_txgen_kernel(const FxTxJob *jobs, const uint32_t *tile_job, const uint32
 }
 
 extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0,
-                                      const float2 *head_syms, const uint8_t *pay_idx, const float2 *sc, float2 *out)
+                                      const uint8_t *head_idx, const uint8_t *pay_idx, const FxTxTables *T, float2 *out)
 {
-    hipLaunchKernelGGL(fx_txgen_kernel, dim3(ntiles), dim3(TX_TILE), 0, st, jobs, tile_job, tile_n0, head_syms, pay_idx, sc, out);
+    hipLaunchKernelGGL(fx_txgen_kernel, dim3(ntiles), dim3(TX_TILE), 0, st, jobs, tile_job, tile_n0, head_idx, pay_idx, T, out);
     return hipGetLastError();
 }
 

@@ -4,8 +4,8 @@
 // flexframegen_assemble (:200) + flexframegen_write_samples (:203-205) with the properties set at :51-56 / :183-189.
 // Modulation and the pulse-shaping interpolator -- all of the float work, 2 x 15 fused multiply-adds per output sample
 // -- run in fx_txgen_kernel; the packet encoding (CRC, whitening, both code stages, interleavers, bit packing, Gray /
-// DPSK index arithmetic) in fx_txenc_kernel.  The 54-byte header packets are encoded on the host (fx_codec.hpp), and so
-// are the payload packets when FXTX_HOST_ENCODE=1 (host threads; they join at the symbol-index stage).  Output is bit-identical to the host generator behind flexframegen_* (fx_dropin.cpp) and to the oracle's
+// DPSK index arithmetic) of header and payload packets in fx_txenc_kernel.  With FXTX_HOST_ENCODE=1 the packets are
+// encoded by fx_codec.hpp on host threads instead and join at the symbol-index stage.  Output is bit-identical to the host generator behind flexframegen_* (fx_dropin.cpp) and to the oracle's
 // fxr_gen_frame.
 #include <hip/hip_runtime.h>
 #include <cstring>
@@ -21,7 +21,7 @@
 #include "fx_codec.hpp"
 
 extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxTxJob *jobs, const uint32_t *tile_job, const uint32_t *tile_n0,
-                                      const float2 *head_syms, const uint8_t *pay_idx, const float2 *sc, float2 *out);
+                                      const uint8_t *head_idx, const uint8_t *pay_idx, const FxTxTables *T, float2 *out);
 extern "C" hipError_t fx_launch_txenc(unsigned njobs, hipStream_t st, const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena,
                                       uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx, const FxTxTables *T);
 extern "C" void fxrx_set_error(const char *msg);       // fx_host.cpp: thread-local message behind fxrx_last_error()
@@ -37,7 +37,7 @@ template <class T> struct Dev {
 struct fxtx_ctx_s {
     int device = 0;
     hipStream_t stream = nullptr;
-    Dev<FxTxTables> d_tab; Dev<float2> d_head; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
+    Dev<FxTxTables> d_tab; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
     // packet encoder on the GPU: payload bytes, scratch, interleaver gather tables (one per coded length, append-only)
     Dev<uint8_t> d_pay, d_bufA, d_bufB; Dev<FxTxEncJob> d_ejobs; Dev<uint32_t> d_perm;
     std::map<uint32_t, uint32_t> perm_off; std::vector<uint32_t> perm_host; size_t perm_uploaded = 0;
@@ -63,6 +63,8 @@ fxtx_ctx *fxtx_create(int device)
     std::memcpy(t->golenc, B.gol_enc, sizeof t->golenc); std::memcpy(t->h128enc, B.h128_enc, sizeof t->h128enc);
     std::memcpy(t->h74enc, B.h74_enc, 16); std::memcpy(t->h84enc, B.h84_enc, 16);
     std::memcpy(t->sdcol, B.sd_col, 64); std::memcpy(t->sd22col, B.sd22_col, 16); std::memcpy(t->sd39col, B.sd39_col, 32);
+    for (int i = 0; i < FX_PN_LEN; i++) t->pn[i] = make_float2(H.pn[i].re, H.pn[i].im);
+    for (int i = 0; i < FX_HDR_PILOTS; i++) t->pilots[i] = make_float2(H.pilots[i].re, H.pilots[i].im);
     std::memcpy(t->rsexp, B.rs_exp, 512); std::memcpy(t->rslog, B.rs_log, 256); std::memcpy(t->rsgen, B.rs_gen, 33);
     if (!c->d_tab.reserve(1) || hipMemcpy(c->d_tab.p, t.get(), sizeof(FxTxTables), hipMemcpyHostToDevice) != hipSuccess) { fxrx_set_error("fxtx_create: table upload failed"); return nullptr; }
     return c.release();
@@ -89,13 +91,25 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
     if (hipSetDevice(c->device) != hipSuccess) { fxrx_set_error("hipSetDevice failed"); return FXRX_ERR_HIP; }
     const unsigned nhead = FX_PN_LEN + FX_HDR_SYM;
     std::vector<FxTxJob> jobs(n_frames);
-    std::vector<float2> head((size_t)n_frames * nhead);
     std::vector<uint8_t> idx; std::vector<uint32_t> tile_job, tile_n0;
     const fx::HostTables &H = fx::host_tables();
-    // pass 1 (serial, cheap): sizes and offsets.  pass 2 (host threads): the byte work of every frame -- CRC, FEC
-    // encoders, interleavers, whitening, bit packing, Gray / DPSK index arithmetic -- a few kilobytes each.
+    // pass 1 (serial, cheap): sizes, offsets, encoder jobs.  pass 2 (host threads): pulse design for fractional delays, and
+    // the packet encoding of frames that do not go through the encoder kernel (FXTX_HOST_ENCODE=1, unsupported schemes).
     uint64_t idx_total = 0, buf_total = 0;
     std::vector<uint8_t> pay; std::vector<FxTxEncJob> ejobs; std::vector<char> on_gpu(n_frames, 0);
+    // gather table of the interleaver of a given length: bit q of the output = bit g[q] of the input (inverse of the
+    // de-interleaver's); built once per length, kept on the device
+    auto perm_for = [&](uint32_t len) -> uint32_t {
+        auto it = c->perm_off.find(len);
+        if (it == c->perm_off.end()) {
+            const std::vector<uint32_t> lab = fx::Interleaver(len).decode_gather();
+            const uint32_t off = (uint32_t)c->perm_host.size();
+            c->perm_host.resize(off + lab.size());
+            for (size_t q = 0; q < lab.size(); q++) c->perm_host[off + lab[q]] = (uint32_t)q;
+            it = c->perm_off.emplace(len, off).first;
+        }
+        return it->second;
+    };
     for (unsigned i = 0; i < n_frames; i++) {
         const fxtx_frame &f = frames[i];
         if (fx::modem_bps(f.props.mod_scheme) == 0 || f.payload_len > 65535u || (!f.payload && f.payload_len)) { fxrx_set_error("fxtx_generate: bad frame description"); return FXRX_ERR_ARG; }
@@ -106,7 +120,7 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
         j.nsym = nhead + j.npay + 2 * FX_M;
         j.ms = f.props.mod_scheme; j.out_off = f.out_offset;
         if (f.out_offset + 2ull * j.nsym > out_len) { fxrx_set_error("fxtx_generate: frame does not fit the output buffer"); return FXRX_ERR_ARG; }
-        j.head_off = i * nhead; j.idx_off = (uint32_t)idx_total;
+        j.idx_off = (uint32_t)idx_total;
         idx_total += j.npay;
         // packet encoding on the GPU (fx_txenc_kernel) unless forced onto the host
         if (!c->host_encode_only && fx::fec_supported(f.props.fec0) && fx::fec_supported(f.props.fec1)) {
@@ -114,18 +128,6 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
             FxTxEncJob e{};
             e.pay_off = (uint32_t)pay.size(); e.n = f.payload_len; e.check = f.props.check; e.fec0 = f.props.fec0; e.fec1 = f.props.fec1;
             e.k = pl.k; e.l0 = pl.l0; e.l1 = pl.l1;
-            auto perm_for = [&](uint32_t len) -> uint32_t {
-                auto it = c->perm_off.find(len);
-                if (it == c->perm_off.end()) {
-                    // gather table of the interleaver: bit q of the output = bit g[q] of the input (inverse of the de-interleaver's)
-                    const std::vector<uint32_t> lab = fx::Interleaver(len).decode_gather();
-                    const uint32_t off = (uint32_t)c->perm_host.size();
-                    c->perm_host.resize(off + lab.size());
-                    for (size_t q = 0; q < lab.size(); q++) c->perm_host[off + lab[q]] = (uint32_t)q;
-                    it = c->perm_off.emplace(len, off).first;
-                }
-                return it->second;
-            };
             e.perm0_off = perm_for(pl.l0); e.perm1_off = perm_for(pl.l1);
             e.buf_off = (uint32_t)buf_total; buf_total += (std::max(pl.l0, pl.l1) + 16 + 15) & ~15u;
             e.idx_off = j.idx_off; e.npay = j.npay; e.ms = j.ms;
@@ -134,15 +136,34 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
         }
         for (uint32_t n0 = 0; n0 < j.nsym; n0 += 256) { tile_job.push_back(i); tile_n0.push_back(n0); }
     }
-    if (idx_total >= (1ull << 32)) { fxrx_set_error("fxtx_generate: batch too large"); return FXRX_ERR_ARG; }
-    idx.assign((size_t)idx_total + 16, 0);
+    // the header symbol words (216 per frame) live behind the payload indices; the header packet (20 bytes, CRC-32,
+    // SECDED(72,64), Hamming(8,4), QPSK) goes through the same encoder kernel as the payload packets
+    const uint64_t head_base = (idx_total + 15) & ~15ull;
+    if (head_base + (uint64_t)FX_HDR_MOD * n_frames >= (1ull << 32)) { fxrx_set_error("fxtx_generate: batch too large"); return FXRX_ERR_ARG; }
+    idx.assign((size_t)(head_base + (uint64_t)FX_HDR_MOD * n_frames) + 16, 0);
+    const fx::PacketPlan hp = fx::packet_plan(FX_HDR_DEC, FX_CRC_32, FX_FEC_SECDED7264, FX_FEC_HAMMING84);
+    for (unsigned i = 0; i < n_frames; i++) {
+        const fxtx_frame &f = frames[i];
+        jobs[i].head_off = (uint32_t)(head_base + (uint64_t)FX_HDR_MOD * i);
+        if (c->host_encode_only) continue;
+        fx::FrameGen g; g.ms = f.props.mod_scheme; g.check = f.props.check; g.fec0 = f.props.fec0; g.fec1 = f.props.fec1;
+        uint8_t hd[FX_HDR_DEC]; g.head_bytes(f.header, f.payload_len, hd);
+        FxTxEncJob e{};
+        e.pay_off = (uint32_t)pay.size(); e.n = FX_HDR_DEC; e.check = FX_CRC_32; e.fec0 = FX_FEC_SECDED7264; e.fec1 = FX_FEC_HAMMING84;
+        e.k = hp.k; e.l0 = hp.l0; e.l1 = hp.l1;
+        e.perm0_off = perm_for(hp.l0); e.perm1_off = perm_for(hp.l1);
+        e.buf_off = (uint32_t)buf_total; buf_total += (std::max(hp.l0, hp.l1) + 16 + 15) & ~15u;
+        e.idx_off = jobs[i].head_off; e.npay = FX_HDR_MOD; e.ms = FX_MODEM_QPSK;
+        pay.insert(pay.end(), hd, hd + FX_HDR_DEC);
+        ejobs.push_back(e);
+    }
     (void)fx::block_codes();                                        // build the shared code tables before the threads start
     auto encode_range = [&](unsigned first, unsigned step) {
         for (unsigned i = first; i < n_frames; i += step) {
             const fxtx_frame &f = frames[i];
             fx::FrameGen g; g.ms = f.props.mod_scheme; g.check = f.props.check; g.fec0 = f.props.fec0; g.fec1 = f.props.fec1;
             FxTxJob &j = jobs[i];
-            g.head(f.header, f.payload_len, reinterpret_cast<fx::cf *>(head.data() + (size_t)i * nhead));
+            if (c->host_encode_only) g.head_words(f.header, f.payload_len, idx.data() + j.head_off);
             if (!on_gpu[i]) {
                 const std::vector<uint8_t> w = g.payload_indices(f.payload, f.payload_len);
                 std::memcpy(idx.data() + j.idx_off, w.data(), w.size());
@@ -159,9 +180,8 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
     }
     if (n_frames == 0) return 0;
     const size_t nt = tile_job.size();
-    if (!c->d_jobs.reserve(n_frames) || !c->d_head.reserve(head.size()) || !c->d_idx.reserve(idx.size()) || !c->d_tiles.reserve(2 * nt)) { fxrx_set_error("hipMalloc failed"); return FXRX_ERR_HIP; }
+    if (!c->d_jobs.reserve(n_frames) || !c->d_idx.reserve(idx.size()) || !c->d_tiles.reserve(2 * nt)) { fxrx_set_error("hipMalloc failed"); return FXRX_ERR_HIP; }
     bool ok = hipMemcpyAsync(c->d_jobs.p, jobs.data(), n_frames * sizeof(FxTxJob), hipMemcpyHostToDevice, c->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(c->d_head.p, head.data(), head.size() * sizeof(float2), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(c->d_idx.p, idx.data(), idx.size(), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(c->d_tiles.p, tile_job.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(c->d_tiles.p + nt, tile_n0.data(), nt * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream) == hipSuccess;
@@ -177,7 +197,7 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
         ok = ok && hipMemcpyAsync(c->d_ejobs.p, ejobs.data(), ejobs.size() * sizeof(FxTxEncJob), hipMemcpyHostToDevice, c->stream) == hipSuccess;
         ok = ok && fx_launch_txenc((unsigned)ejobs.size(), c->stream, c->d_ejobs.p, c->d_pay.p, c->d_perm.p, c->d_bufA.p, c->d_bufB.p, c->d_idx.p, c->d_tab.p) == hipSuccess;
     }
-    ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_head.p, c->d_idx.p, reinterpret_cast<const float2 *>(c->d_tab.p) /* FxTxTables::sc is its first member */, (float2 *)out_device) == hipSuccess;
+    ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_idx.p, c->d_idx.p, c->d_tab.p, (float2 *)out_device) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;       // the staging vectors above are pageable and die with this call
     if (!ok) { fxrx_set_error(std::string("fxtx_generate: ") .append(hipGetErrorString(hipGetLastError())).c_str()); return FXRX_ERR_HIP; }
     return 0;

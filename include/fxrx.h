@@ -206,9 +206,9 @@ int fxrx_outer_from_index(int idx); int fxrx_outer_to_index(unsigned int fec);
  *
  * What /root/reference/lib/flex_tx_impl.cc:191-209 (send_pkt) does per PDU -- flexframegen_assemble (:200) and
  * flexframegen_write_samples (:203-205) with the properties of :51-56 / :183-189 -- for many frames in one call,
- * straight into a device buffer.  Packet encoding (CRC, whitening, both code stages, interleavers, bit packing),
- * modulation and pulse shaping run on the GPU; only the 54-byte header packets are encoded on the host inside the
- * call.  Samples are bit-identical to flexframegen_write_samples.
+ * straight into a device buffer.  Packet encoding of header and payload (CRC, whitening, both code stages,
+ * interleavers, bit packing), modulation and pulse shaping run on the GPU; the host lays out descriptors.  Samples are
+ * bit-identical to flexframegen_write_samples.
  * ------------------------------------------------------------------------------------------ */
 typedef struct fxtx_ctx_s fxtx_ctx;
 typedef struct {
