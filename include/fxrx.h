@@ -189,7 +189,9 @@ typedef struct {
     uint64_t walk_mode;                          /* 0 walked with known state, 1 speculatively across the block boundary, 2 re-staged */       /* hops re-checked / streams walked again because a skipped hop fired */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
-/* the HIP stream all kernels of this context are launched on (hipStream_t as void*) */
+/* the first of the context's two walk streams (hipStream_t as void*): input staging, walkers and seek verification of the
+ * even slots run on it; payload kernels run on per-slot payload streams.  To order external work against a block, use
+ * fxrx_collect (it returns when the block's results are on the host). */
 void *fxrx_stream(const fxrx_ctx *c);
 
 /* batched frame generator: one frame -> samples (host) */
