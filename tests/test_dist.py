@@ -48,3 +48,44 @@ def test_shard_streams_covers_everything_once():
     for total, world in ((1024, 8), (1000, 8), (7, 4), (8, 8), (3, 8)):
         got = sum((bench.shard_streams(total, r, world) for r in range(world)), [])
         assert got == list(range(total))
+
+
+def _run_bench(args, env_extra, timeout=240):
+    env = dict(os.environ, BENCH_STUB="1", **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        if k not in env_extra: env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_gpus_flag_spawns_ranks_over_gloo():
+    """`python bench.py --gpus 2` with no launcher: main() starts two fresh rank processes itself (RANK / WORLD_SIZE /
+    MASTER_* set), they rendezvous (gloo here; the GPU part is stubbed by BENCH_STUB=1), rank 0 prints the line with
+    n_gpus = 2; the timed region is stretched to --min-time by repeating the K-step schedule."""
+    r = _run_bench(["--gpus", "2", "--steps", "4", "--warmup", "1", "--min-time", "0.2"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout                         # ONE line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["data"] == "stub" and d["scaling"] == "weak"
+    assert d["steps"] == 4 and d["repeats"] >= 2 and d["passes_timed"] == 4 * d["repeats"]
+    # max over ranks: rank 1's stub step is twice as slow as rank 0's, and the whole region lasted >= min-time
+    assert d["ms_per_step"] * d["passes_timed"] >= 190.0
+    assert d["ms_per_step"] >= 0.9
+
+
+def test_bench_under_a_launcher_checks_world_size():
+    """Ranks from the environment (torch.distributed.run style): --gpus must agree with WORLD_SIZE, loudly."""
+    r = _run_bench(["--gpus", "8", "--steps", "2"], dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
+    r = _run_bench(["--gpus", "1", "--steps", "2", "--min-time", "0.01"], dict(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"))
+    assert r.returncode == 0 and json.loads(r.stdout.strip().splitlines()[-1])["n_gpus"] == 1
+
+
+def test_bench_repeat_count():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.choose_repeats(0.001, 20, 1.0) == 50
+    assert bench.choose_repeats(0.001, 200, 0.1) == 1
+    assert bench.choose_repeats(0.0, 20, 1.0) == 1
+    e = bench.rank_env(3, 8, 1234, base={})
+    assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "1234")
