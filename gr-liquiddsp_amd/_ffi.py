@@ -67,7 +67,7 @@ class Timing(C.Structure):                  # fxrx_timing
 # every symbol include/fxrx.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
     "flexframesync_create", "flexframesync_destroy", "flexframesync_execute", "flexframesync_reset",
-    "fxrx_sync_flush", "fxrx_sync_set_block", "fxrx_sync_set_threshold", "fxrx_sync_pending",
+    "fxrx_sync_flush", "fxrx_sync_set_block", "fxrx_sync_set_threshold", "fxrx_sync_pending", "fxrx_sync_errors", "fxrx_qdet_errors",
     "msequence_create", "msequence_advance", "msequence_destroy",
     "qdetector_cccf_create_linear", "qdetector_cccf_destroy", "qdetector_cccf_set_threshold",
     "qdetector_cccf_execute", "qdetector_cccf_get_tau", "qdetector_cccf_get_gamma", "qdetector_cccf_get_dphi",
@@ -145,6 +145,8 @@ def lib():
     L.fxrx_sync_set_block.argtypes = [C.c_void_p, C.c_uint]; L.fxrx_sync_set_block.restype = None
     L.fxrx_sync_set_threshold.argtypes = [C.c_void_p, C.c_float]; L.fxrx_sync_set_threshold.restype = None
     L.fxrx_sync_pending.argtypes = [C.c_void_p]; L.fxrx_sync_pending.restype = C.c_uint
+    L.fxrx_sync_errors.argtypes = [C.c_void_p]; L.fxrx_sync_errors.restype = C.c_uint
+    L.fxrx_qdet_errors.argtypes = [C.c_void_p]; L.fxrx_qdet_errors.restype = C.c_uint
     L.msequence_create.restype = C.c_void_p; L.msequence_create.argtypes = [C.c_uint] * 3
     L.msequence_advance.restype = C.c_uint; L.msequence_advance.argtypes = [C.c_void_p]
     L.msequence_destroy.argtypes = [C.c_void_p]; L.msequence_destroy.restype = None

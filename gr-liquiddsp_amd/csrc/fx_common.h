@@ -69,7 +69,8 @@ enum {
     FX_EXIT_PAYLOAD = 2,     // last frame descriptor is incomplete: payload runs past the end of data
     FX_EXIT_TABLE_FULL = 3   // frame table exhausted: resume at (pos, fresh, floor)
 };
-enum { FX_FLAG_HEADER_VALID = 1, FX_FLAG_INCOMPLETE = 2, FX_FLAG_EXACT = 4 /* walker was in exact (locked) mode */ };
+enum { FX_FLAG_HEADER_VALID = 1, FX_FLAG_INCOMPLETE = 2, FX_FLAG_EXACT = 4 /* walker was in exact (locked) mode */,
+       FX_FLAG_FLOOR_CLEAR = 8 /* the walker's zero-floor was <= start at detection: no sample the frame reads was masked */ };
 
 struct FxWalkJob {
     const float2 *x;        // stream samples; logical index 0 == x[0]
@@ -117,6 +118,7 @@ struct FxWalkResult {
     float    handoff_rxy; uint32_t hops_cheap;
     int64_t  tail_pos, tail_floor;   // the seek in progress at exit started here: hops [tail_pos, end) saw nothing,
     int64_t  handoff_pos;            // end = handoff_pos (hop of the hand-off detection) or pos
+    uint32_t handoff_clear, pad_;    // the hand-off detection saw nothing masked by the floor (floor <= handoff_start)
     uint32_t stamp[4];      // diagnostic builds: shader clocks in coarse scan / exact seek / align / header
 };
 

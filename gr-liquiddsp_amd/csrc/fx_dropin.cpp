@@ -4,6 +4,9 @@
 #include <memory>
 #include <vector>
 #include <cstring>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
 #include "../../include/fxrx.h"
 #include "fx_codec.hpp"
 
@@ -24,10 +27,20 @@ struct fxrx_sync_s {
     std::vector<fx_complex> queue; unsigned block = 1u << 16;
     std::deque<HeldFrame> pending; HeldFrame current;
 
-    void run()
+    unsigned errors = 0;
+    // returns false when the GPU call failed: the samples stay queued (they run again with the next call), the error
+    // text stays in fxrx_last_error(), one line goes to stderr, `errors` counts
+    bool run()
     {
         const void *p = queue.data(); uint64_t n = queue.size();
-        int nr = fxrx_process(ctx, &p, &n, 0);
+        int nr = ctx ? fxrx_process(ctx, &p, &n, 0) : FXRX_ERR_STATE;
+        if (nr < 0) {
+            if (errors++ == 0 || (errors & (errors - 1)) == 0)
+                std::fprintf(stderr, "libfxrx: flexframesync_execute: block of %llu samples failed (%d): %s [%u failures so far]\n",
+                             (unsigned long long)n, nr, ctx ? fxrx_last_error() : "no context", errors);
+            if (queue.size() > (size_t)64 * block) queue.erase(queue.begin(), queue.end() - (std::ptrdiff_t)(32 * (size_t)block));   // bounded
+            return false;
+        }
         queue.clear();
         for (int i = 0; i < nr; i++) {
             fxrx_frame f; if (fxrx_result(ctx, (unsigned)i, &f) != 0) continue;
@@ -39,6 +52,7 @@ struct fxrx_sync_s {
             h.stats.mod_scheme = f.mod_scheme; h.stats.mod_bps = f.mod_bps; h.stats.check = f.check; h.stats.fec0 = f.fec0; h.stats.fec1 = f.fec1;
             pending.push_back(std::move(h));
         }
+        return true;
     }
     void deliver_one()
     {
@@ -72,20 +86,24 @@ void flexframesync_execute(flexframesync q, fx_complex *x, unsigned int n)
 {
     if (!q) return;
     if (n) q->queue.insert(q->queue.end(), x, x + n);
-    if (q->queue.size() >= q->block) q->run();
+    if (q->queue.size() >= q->block) (void)q->run();
     q->deliver_one();
 }
-void fxrx_sync_flush(flexframesync q) { if (!q) return; if (!q->queue.empty()) q->run(); }
+void fxrx_sync_flush(flexframesync q) { if (!q) return; if (!q->queue.empty()) (void)q->run(); }
 void fxrx_sync_set_block(flexframesync q, unsigned int samples) { if (q) q->block = samples ? samples : 1; }
 unsigned int fxrx_sync_pending(flexframesync q) { return q ? (unsigned)q->pending.size() : 0; }
+unsigned int fxrx_sync_errors(flexframesync q) { return q ? q->errors : 0; }
 void fxrx_sync_set_threshold(flexframesync q, float t)
 {
-    // the threshold lives in the context configuration: recreate it (state is reset, as liquid's setter does not promise otherwise)
+    // the threshold lives in the context configuration: make a new context first, swap only if that worked (state is
+    // reset, as liquid's setter does not promise otherwise); on failure the old context stays and the error is reported
     if (!q) return;
-    fxrx_destroy(q->ctx);
     fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1; cfg.threshold = t;
     if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
-    q->ctx = fxrx_create(&cfg);
+    fxrx_ctx *nc = fxrx_create(&cfg);
+    if (!nc) { q->errors++; std::fprintf(stderr, "libfxrx: fxrx_sync_set_threshold: %s (threshold unchanged)\n", fxrx_last_error()); return; }
+    fxrx_destroy(q->ctx);
+    q->ctx = nc;
 }
 
 }  // extern "C"
@@ -110,17 +128,27 @@ struct fxrx_qdet_s {
     std::deque<fxrx_frame> pending;
     fx_complex window[FX_NFFT];
     float tau = 0, gamma = 0, dphi = 0, phi = 0;
-    void make_ctx()
+    unsigned errors = 0;
+    bool make_ctx()                     // a failed re-creation keeps the old context
     {
-        if (ctx) fxrx_destroy(ctx);
         fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_DETECTOR; cfg.n_streams = 1; cfg.threshold = threshold;
         if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
-        ctx = fxrx_create(&cfg);
+        fxrx_ctx *nc = fxrx_create(&cfg);
+        if (!nc) { errors++; std::fprintf(stderr, "libfxrx: qdetector_cccf: %s\n", fxrx_last_error()); return false; }
+        if (ctx) fxrx_destroy(ctx);
+        ctx = nc;
+        return true;
     }
     void run()
     {
         const void *p = hist.data() + fed; uint64_t n = hist.size() - fed;
         int nr = fxrx_process(ctx, &p, &n, 0);
+        if (nr < 0) {                   // samples stay un-fed: they run again with the next block
+            if (errors++ == 0 || (errors & (errors - 1)) == 0)
+                std::fprintf(stderr, "libfxrx: qdetector_cccf_execute: block of %llu samples failed (%d): %s [%u failures so far]\n",
+                             (unsigned long long)n, nr, fxrx_last_error(), errors);
+            return;
+        }
         fed = hist.size();
         for (int i = 0; i < nr; i++) { fxrx_frame f; if (fxrx_result(ctx, (unsigned)i, &f) == 0) pending.push_back(f); }
     }
@@ -140,7 +168,15 @@ qdetector_cccf qdetector_cccf_create_linear(fx_complex *seq, unsigned int len, i
 // /root/reference/lib/frame_detector_cc_impl.cc:63
 void qdetector_cccf_destroy(qdetector_cccf q) { if (!q) return; fxrx_destroy(q->ctx); delete q; }
 // /root/reference/lib/frame_detector_cc_impl.cc:55
-void qdetector_cccf_set_threshold(qdetector_cccf q, float t) { if (!q) return; q->threshold = t; q->make_ctx(); q->hist.clear(); q->hist_base = 0; q->fed = 0; q->pending.clear(); }
+void qdetector_cccf_set_threshold(qdetector_cccf q, float t)
+{
+    if (!q) return;
+    const float old = q->threshold;
+    q->threshold = t;
+    if (!q->make_ctx()) { q->threshold = old; return; }
+    q->hist.clear(); q->hist_base = 0; q->fed = 0; q->pending.clear();
+}
+unsigned int fxrx_qdet_errors(qdetector_cccf q) { return q ? q->errors : 0; }
 // /root/reference/lib/frame_detector_cc_impl.cc:77
 void *qdetector_cccf_execute(qdetector_cccf q, fx_complex x)
 {

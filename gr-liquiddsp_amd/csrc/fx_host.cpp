@@ -584,8 +584,11 @@ static int stitch_stream(fxrx_ctx_s *c, Slot &sl, unsigned s)
             while (nxt + 1 < first_job[s + 1] && R.handoff_start >= sl.jobs[nxt].stop + FX_HOP) nxt++;
             const FxWalkResult &RN = sl.h_res.p[nxt]; const FxFrame *FN = sl.h_frames.p + sl.jobs[nxt].frame_base;
             uint32_t found = UINT32_MAX;
-            for (uint32_t i = 0; i < RN.n_frames; i++)
-                if ((FN[i].flags & FX_FLAG_EXACT) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; break; }
+            // A frame is a function of (start, CFO bin) alone only if no sample it reads was masked by a zero-floor: the
+            // true chain may detect with start < floor (window half zeros after a reset), a speculative walker reaches the
+            // same (start, bin) with another floor.  Splice only when both floors lie at or below the start; else repair.
+            for (uint32_t i = 0; R.handoff_clear && i < RN.n_frames; i++)
+                if ((FN[i].flags & FX_FLAG_EXACT) && (FN[i].flags & FX_FLAG_FLOOR_CLEAR) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; break; }
             if (found != UINT32_MAX) {
                 splice_rxy = R.handoff_rxy; spliced = true; tpos = R.pos; tfloor = R.floor; tfresh = R.fresh != 0;
                 cur = nxt; m = found; R = RN; F = FN; continue;

@@ -245,7 +245,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     int64_t pos = job.start, floor_ = job.floor;
     bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
     uint32_t nfr = 0, hops = 0, hops_cheap = 0, exact_left = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
-    int64_t ho_start = 0, ho_pos = 0; int32_t ho_off = 0; float ho_rxy = 0.0f;
+    int64_t ho_start = 0, ho_pos = 0; int32_t ho_off = 0; float ho_rxy = 0.0f; uint32_t ho_clear = 0;
     float x2_0 = 0.0f;
     // A locked flex_rx walker may skip hops its coarse scan finds empty (job.no_skip == 0): it stays on the true hop
     // grid and runs the exact detector only around coarse-scan candidates; the host has every hop between
@@ -430,7 +430,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         }
 
         const int64_t a0 = pos - FX_HOP + (int64_t)bidx;
-        if (in_handoff) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = pos; exit_code = FX_EXIT_STOP; break; }
+        if (in_handoff) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = pos; ho_clear = floor_ <= a0 ? 1u : 0u; exit_code = FX_EXIT_STOP; break; }
         if (nfr >= job.max_frames) { exit_code = FX_EXIT_TABLE_FULL; break; }
         if (a0 + FX_NFFT > n) { exit_code = FX_EXIT_NEED_DATA; break; }
 
@@ -518,7 +518,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
         fr.seek_pos = span_pos; fr.seek_floor = span_floor; fr.det_pos = pos;
         fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
-        fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f; fr.flags = 0;
+        fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f; fr.flags = floor_ <= a0 ? FX_FLAG_FLOOR_CLEAR : 0u;
         fr.pay_len = fr.ms = fr.check = fr.fec0 = fr.fec1 = fr.pay_sym_len = 0;
 #pragma unroll
         for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = 0;
@@ -678,7 +678,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
         r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
         r.handoff_rxy = ho_rxy; r.hops_cheap = hops_cheap;
-        r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos;
+        r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos; r.handoff_clear = ho_clear; r.pad_ = 0;
 #ifdef FX_STAMPS
         for (int i = 0; i < 4; i++) r.stamp[i] = wst_[i];
 #else

@@ -25,8 +25,14 @@
 extern "C" {
 #endif
 
-/* liquid's `float complex` is two packed floats; gr_complex (std::complex<float>) likewise. */
+/* liquid's `float complex` is two packed floats; gr_complex (std::complex<float>) likewise.  A caller that wants its own
+ * spelling of that type in these prototypes defines FXRX_COMPLEX_TYPE before including this header (include/liquid/liquid.h
+ * does: std::complex<float> in C++, float _Complex in C); layout and calling convention are the same. */
+#ifdef FXRX_COMPLEX_TYPE
+typedef FXRX_COMPLEX_TYPE fx_complex;
+#else
 typedef struct { float re, im; } fx_complex;
+#endif
 
 /* ------------------------------------------------------------------------------------------
  * (1) drop-in names
@@ -68,6 +74,9 @@ void fxrx_sync_flush(flexframesync q);
 void fxrx_sync_set_block(flexframesync q, unsigned int samples);
 void fxrx_sync_set_threshold(flexframesync q, float threshold);
 unsigned int fxrx_sync_pending(flexframesync q);     /* completed frames not yet delivered */
+/* the liquid signatures return void: a block that failed on the GPU keeps its samples queued (they run again with the
+ * next call), the text stays in fxrx_last_error(), one line goes to stderr and this counter goes up */
+unsigned int fxrx_sync_errors(flexframesync q);
 
 /* m-sequence -- /root/reference/lib/frame_detector_cc_impl.cc:47,49,50,52 */
 typedef struct fxrx_mseq_s *msequence;
@@ -93,6 +102,7 @@ float  qdetector_cccf_get_gamma(qdetector_cccf q);
 float  qdetector_cccf_get_dphi(qdetector_cccf q);
 float  qdetector_cccf_get_phi(qdetector_cccf q);
 unsigned int qdetector_cccf_get_buf_len(qdetector_cccf q);
+unsigned int fxrx_qdet_errors(qdetector_cccf q);     /* as fxrx_sync_errors */
 
 /* frame generator (test / loopback source) -- /root/reference/lib/flex_tx_impl.cc:51,56,72,188,198-201 */
 typedef struct { unsigned int check, fec0, fec1, mod_scheme; } flexframegenprops_s;

@@ -129,3 +129,40 @@ def test_cpp_block_shells_compile_against_the_header(fx, tmp_path):
     if fx.lib().fxrx_device_count() == 0:
         r = subprocess.run([exe], capture_output=True, text=True)
         assert r.returncode != 0 and "no usable HIP device" in r.stderr
+
+
+def _build_callsites(tmp_path, std="c++11"):
+    import subprocess
+    exe = str(tmp_path / "test_reference_callsites")
+    lib = os.path.join(ROOT, "gr-liquiddsp_amd", "csrc")
+    subprocess.check_call(["g++", "-std=" + std, "-Wall", "-Werror", "-O1", "-I" + os.path.join(ROOT, "include"), "-o", exe,
+                           os.path.join(ROOT, "tests", "cpp", "test_reference_callsites.cpp"), "-L" + lib, "-lfxrx", "-Wl,-rpath," + lib])
+    return exe
+
+
+@pytest.mark.parametrize("std", ["c++11", "c++17"])
+def test_reference_call_sites_compile_through_the_liquid_shim(fx, tmp_path, std):
+    """include/liquid/liquid.h lets the reference's call sequences compile as written (gr_complex* / gr_complex by value /
+    framesyncstats_s fields) and link against libfxrx.so alone: tests/cpp/test_reference_callsites.cpp.  Running it needs
+    a GPU (tests/test_gpu_parity.py); here it must at least build, link, and fail loudly without a device."""
+    import subprocess
+    exe = _build_callsites(tmp_path, std)
+    r = subprocess.run([exe, "--link-only"], capture_output=True, text=True)
+    assert r.returncode == 0 and "LINKED" in r.stdout
+    if fx.lib().fxrx_device_count() == 0:
+        r = subprocess.run([exe], capture_output=True, text=True)
+        assert r.returncode == 2 and "no usable HIP device" in r.stderr
+
+
+def test_liquid_shim_is_valid_c(tmp_path):
+    """The same header from C (float _Complex), as liquid.h is a C header first."""
+    import subprocess
+    src = tmp_path / "shim_c.c"
+    src.write_text("#include <liquid/liquid.h>\n"
+                   "static int cb(unsigned char *h, int hv, unsigned char *p, unsigned int n, int pv, framesyncstats_s st, void *ud)\n"
+                   "{ (void)h; (void)hv; (void)p; (void)n; (void)pv; (void)ud; return (int)crealf(st.framesyms[0]); }\n"
+                   "int f(liquid_float_complex *x) { flexframesync q = flexframesync_create(cb, 0); flexframesync_execute(q, x, 256);\n"
+                   "  qdetector_cccf d = qdetector_cccf_create_linear(x, 64, LIQUID_FIRFILT_ARKAISER, 2, 7, 0.3f);\n"
+                   "  flexframegenprops_s p; flexframegenprops_init_default(&p); p.check = LIQUID_CRC_24; p.fec0 = LIQUID_FEC_CONV_V27;\n"
+                   "  return qdetector_cccf_execute(d, x[0]) != 0; }\n")
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-c", str(src), "-o", str(tmp_path / "shim_c.o")])

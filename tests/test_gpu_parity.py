@@ -274,6 +274,20 @@ def test_cpp_block_shells_loopback(fx, tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
 
 
+def test_reference_call_sites_run_through_the_liquid_shim(fx, tmp_path):
+    """tests/cpp/test_reference_callsites.cpp: the liquid calls of lib/flex_rx_impl.cc:49,71,181-201,213,
+    lib/frame_detector_cc_impl.cc:46-55,63,77 and lib/flex_tx_impl.cc:51-56,188,198-201, with the reference's argument types,
+    compiled against include/liquid/liquid.h and libfxrx.so only: TX -> channel -> 256-sample execute calls -> payloads."""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_reference_callsites")
+    lib = os.path.join(root, "gr-liquiddsp_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-O1", "-I" + os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "cpp", "test_reference_callsites.cpp"), "-L" + lib, "-lfxrx", "-Wl,-rpath," + lib])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout + r.stderr
+
+
 def test_dropin_qdetector_and_msequence(fx, oracle):
     """The per-sample liquid names frame_detector_cc calls (lib/frame_detector_cc_impl.cc:47-55,63,77): every detection
     is reported exactly once with the oracle's estimates; the returned pointer holds the 512 aligned samples."""
