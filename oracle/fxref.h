@@ -165,6 +165,7 @@ fxr_sync *fxr_sync_create(fxr_callback cb, void *userdata);
 void      fxr_sync_destroy(fxr_sync *q);
 void      fxr_sync_reset(fxr_sync *q);
 void      fxr_sync_execute(fxr_sync *q, const fxr_c32 *x, unsigned n);
+void      fxr_sync_execute_chunked(fxr_sync *q, const fxr_c32 *x, uint64_t n, unsigned chunk);   /* n samples in calls of `chunk` */
 void      fxr_sync_set_threshold(fxr_sync *q, float t);
 /* introspection used by parity tests: estimates of the most recent frame */
 typedef struct {

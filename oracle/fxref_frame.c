@@ -489,3 +489,9 @@ static void sync_run(fxr_sync *q, const fxr_c32 *x, unsigned n, int top)
 }
 
 void fxr_sync_execute(fxr_sync *q, const fxr_c32 *x, unsigned n) { sync_run(q, x, n, 1); }
+
+/* the caller's loop of /root/reference/lib/flex_rx_impl.cc:212-215: `chunk` samples per execute call */
+void fxr_sync_execute_chunked(fxr_sync *q, const fxr_c32 *x, uint64_t n, unsigned chunk)
+{
+    for (uint64_t i = 0; i < n; i += chunk) sync_run(q, x + i, (unsigned)((n - i) < chunk ? (n - i) : chunk), 1);
+}

@@ -106,6 +106,7 @@ def lib():
         L.fxr_sync_reset.argtypes = [C.c_void_p]
         L.fxr_sync_set_threshold.argtypes = [C.c_void_p, C.c_float]
         L.fxr_sync_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
+        L.fxr_sync_execute_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint]
         L.fxr_sync_last_frame.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
         L.fxr_init()
         _lib = L
@@ -182,9 +183,7 @@ class Sync:
         if chunk is None:
             self.L.fxr_sync_execute(self.q, x.ctypes.data, n)
         else:
-            base = x.ctypes.data
-            for i in range(0, n, chunk):
-                self.L.fxr_sync_execute(self.q, base + 8 * i, min(chunk, n - i))
+            self.L.fxr_sync_execute_chunked(self.q, x.ctypes.data, n, chunk)      # the 256-sample loop, in C like the reference's
         return self.frames
 
     def close(self):
