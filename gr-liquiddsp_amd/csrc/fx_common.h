@@ -61,20 +61,38 @@ enum {
     FX_MODEM_QAM16 = 27, FX_MODEM_QAM32 = 28, FX_MODEM_QAM64 = 29, FX_MODEM_QPSK = 40
 };
 
-// ---- walker job / result records (device memory, written by fx_walk_kernel) ----
+// ---- walker job / result records ----
+// Coordinates: every block of a stream has its own origin, logical index 0 = the first NEW sample of the block.  The
+// tail the previous block left unconsumed sits at negative indices, right-aligned in a carry buffer: index p < 0 reads
+// xa_end[p].  Nothing below the zero-floor (samples before the last synchroniser reset) is ever read.
 enum { FX_MODE_FLEXRX = 0, FX_MODE_DETECT = 1 };
 enum {
     FX_EXIT_STOP = 0,        // reached job.stop, hand-off target recorded (or not requested)
     FX_EXIT_NEED_DATA = 1,   // ran out of samples in SEEK/ALIGN/header: resume at (pos, fresh, floor)
     FX_EXIT_PAYLOAD = 2,     // last frame descriptor is incomplete: payload runs past the end of data
-    FX_EXIT_TABLE_FULL = 3   // frame table exhausted: resume at (pos, fresh, floor)
+    FX_EXIT_TABLE_FULL = 3,  // frame table exhausted: resume at (pos, fresh, floor)
+    FX_EXIT_INVALID = 4      // the state this walker was to start from does not exist (see FxStreamState.invalid)
 };
 enum { FX_FLAG_HEADER_VALID = 1, FX_FLAG_INCOMPLETE = 2, FX_FLAG_EXACT = 4 /* walker was in exact (locked) mode */,
-       FX_FLAG_FLOOR_CLEAR = 8 /* the walker's zero-floor was <= start at detection: no sample the frame reads was masked */ };
+       FX_FLAG_FLOOR_CLEAR = 8 /* the walker's zero-floor was <= start at detection: no sample the frame reads was masked */,
+       FX_FLAG_SPAN_BAD = 16   /* set by fx_seekverify_kernel: the exact detector fires on a hop this frame's seek skipped */,
+       FX_FLAG_SEEK_FRESH = 32 /* the seek that led here started from a freshly reset detector */,
+       FX_FLAG_SPAN_EXACT = 64 /* that seek ran the exact detector on every hop: nothing to verify */ };
+
+// per-stream state a block leaves to its successor (device memory; the chain kernel also mirrors it to the host)
+struct FxStreamState {
+    int64_t  pos, floor;    // resume hop / zero-floor in the NEXT block's coordinates (<= 0)
+    int64_t  carry_len;     // samples kept, right-aligned at the end of the carry buffer the next block reads
+    uint32_t fresh;         // the detector restarts freshly reset at pos
+    uint32_t invalid;       // no state: the tail did not fit the carry buffer (overflow, set by this block) or the state
+    uint32_t overflow;      //   this block started from was itself invalid.  The host replays the blocks behind it.
+    uint32_t pad_;
+};
 
 struct FxWalkJob {
-    const float2 *x;        // stream samples; logical index 0 == x[0]
-    int64_t  n;             // samples available
+    const float2 *x;        // new samples of the block; logical index 0 == x[0]
+    const float2 *xa_end;   // end of the carried tail (index p < 0 reads xa_end[p]); NULL: none
+    int64_t  n;             // new samples
     int64_t  start;         // first new-half position (detector restarts / resumes here)
     int64_t  stop;          // segment end: no new detection is *started* at pos >= stop
     int64_t  floor;         // samples below this index read as zero (last synchroniser reset)
@@ -87,8 +105,11 @@ struct FxWalkJob {
     uint32_t max_frames;    // slots available
     float    threshold;
     uint32_t no_skip;       // 1: a locked flex_rx walker runs the full detector on every hop (exact by itself);
-                            // 0: it may skip hops its coarse scan finds empty -- the host then has every skipped hop
-                            //    checked by fx_seekverify_kernel before it trusts the chain
+                            // 0: it may skip hops its coarse scan finds empty -- every skipped hop is then re-checked
+                            //    by fx_seekverify_kernel before fx_chain_kernel trusts the span
+    const FxStreamState *state_in;   // non-NULL: true walker of a continuing stream: start / floor / fresh come from here
+    uint32_t stream;
+    uint32_t verify_per;    // hops per verification run
 };
 
 struct FxFrame {            // 152 bytes
@@ -118,20 +139,66 @@ struct FxWalkResult {
     float    handoff_rxy; uint32_t hops_cheap;
     int64_t  tail_pos, tail_floor;   // the seek in progress at exit started here: hops [tail_pos, end) saw nothing,
     int64_t  handoff_pos;            // end = handoff_pos (hop of the hand-off detection) or pos
-    uint32_t handoff_clear, pad_;    // the hand-off detection saw nothing masked by the floor (floor <= handoff_start)
+    uint32_t handoff_clear;          // the hand-off detection saw nothing masked by the floor (floor <= handoff_start)
+    uint32_t tail_flags;             // FX_FLAG_SEEK_FRESH / FX_FLAG_SPAN_EXACT of the seek in progress at exit;
+                                     // FX_FLAG_SPAN_BAD is or-ed in by fx_seekverify_kernel
     uint32_t stamp[4];      // diagnostic builds: shader clocks in coarse scan / exact seek / align / header
 };
 
-// ---- seek verification (fx_seekverify_kernel): a run of consecutive detector hops that must all come up empty ----
-struct FxVerifyJob {
-    const float2 *x; int64_t n;
+// ---- seek verification (fx_seekverify_kernel): a run of consecutive detector hops that must all come up empty.  The
+// walkers emit the runs themselves as they close a seek span (atomic counter in the block header). ----
+struct FxVerifyRun {
     int64_t  pos;           // first hop (new-half start); hop h sits at pos + 256 h
     int64_t  floor;
-    uint32_t nhops; float threshold;
+    uint32_t job;           // walk job the span belongs to (sample pointers, threshold)
+    uint32_t owner;         // frame-table slot whose seek span this is; 0x80000000 | job: that job's tail span
+    uint32_t nhops, pad_;
 };
-struct FxVerifyResult {
-    uint32_t det_hop;       // first hop of the run on which the detector fires, 0xFFFFFFFF if none
-    uint32_t bidx; int32_t boff; float peak;
+
+// ---- one stream of a block, as fx_chain_kernel sees it ----
+struct FxStreamDesc {
+    const float2 *x, *xa_end; int64_t n;
+    uint32_t first_job, n_jobs;
+    uint32_t chain_base, chain_cap;      // this stream's region of the chain table
+    uint32_t repair_base, repair_cap;    // frame-table region for walks the chain kernel does itself
+    const FxStreamState *state_in;       // NULL: the stream starts freshly reset at 0
+    FxStreamState *state_out, *state_out_host;
+    float2  *carry_out_end;              // the tail goes to carry_out_end[-carry_len, 0)
+    int64_t  carry_cap;
+    int64_t  abs_base;                   // absolute index (since the last reset) of logical sample 0
+};
+
+enum { FX_BLK_INVALID = 1 /* some stream started from an invalid state: nothing in this block counts */,
+       FX_BLK_CARRY_OVERFLOW = 2, FX_BLK_CHAIN_FULL = 4 /* chain table exhausted (sizing bug) */ };
+#define FX_PLL_CLASSES 12
+struct FxBlockHdr {                      // device memory, zeroed at submit; mirrored to the host by fx_plan_kernel
+    uint32_t n_runs;                     // verification runs emitted (may exceed the capacity: the excess spans are marked bad)
+    uint32_t flags;
+    uint32_t n_frames, n_pjobs, n_mfblk, n_dec_plain, n_dec_rs, pad0_;
+    uint32_t pll_cnt[FX_PLL_CLASSES];    // frames per modulation class
+    uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
+    uint64_t sym_total, byte_total, dw_total, out_total;
+    uint32_t hops, hops_cheap, repairs, verify_hops, verify_failures, walk_jobs_run;
+    uint32_t stream_frames0;             // (scratch)
+    uint32_t done;                       // host mirror only: written last
+    uint32_t stamp[8];
+};
+
+// ---- one result record per chain frame, written straight into pinned host memory ----
+struct FxOutRec {
+    int64_t  start;                      // absolute sample index of aligned sample 0
+    uint32_t stream; int32_t offset;
+    float    rxy, tau, gamma, dphi, phi;
+    uint32_t pfb;
+    float    pilot_dphi, pilot_phi, pilot_gain;
+    uint32_t flags;                      // FX_FLAG_HEADER_VALID
+    uint32_t pay_len, ms, check, fec0, fec1, nsym, bps;
+    uint32_t sym_off, out_off;           // payload symbols / decoded bytes of this frame in the block's arenas
+    float    evm_sum;                    // fx_paypll_kernel
+    uint32_t payload_valid;              // fx_paydec_kernel
+    uint32_t status;
+    uint8_t  header[FX_HDR_DEC];
+    uint32_t pad_[1];
 };
 
 // ---- frame generator (fx_txgen_kernel) ----
@@ -166,9 +233,9 @@ struct FxTxTables {
     float2   pn[FX_PN_LEN], pilots[16];
 };
 
-// ---- payload stage records ----
-struct FxPayJob {           // one per valid, complete frame
-    const float2 *x;        // stream base
+// ---- payload stage records (built on the device by fx_plan_kernel) ----
+struct FxPayJob {           // one per chain frame; nsym == 0: no payload stage (header invalid / detector mode)
+    const float2 *x, *xa_end;   // stream samples (two pieces, see FxWalkJob)
     int64_t  start;         // aligned sample 0
     uint32_t mix_th, mix_dl; float mf_scale;
     uint32_t pfb; int32_t mfc0;
@@ -180,16 +247,12 @@ struct FxPayJob {           // one per valid, complete frame
     uint32_t pay_len, check, fec0, fec1;
     uint32_t k;             // pay_len + crc_len
     uint32_t l0, l1;        // bytes after fec0 / after fec1
-    uint32_t perm0_off, perm1_off;   // offsets into the permutation arena (bit gather tables)
     uint32_t byte_off;      // offset of this frame's scratch in the byte arenas (stride >= l1+8)
     uint32_t dw_off;        // offset in the decision-word arena (u64 units)
     uint32_t out_off;       // offset of decoded payload in the output arena
+    uint32_t pad_;
 };
 
-struct FxPayResult {
-    float    evm_sum;
-    uint32_t payload_valid;
-    uint32_t status;        // 0 ok, 1 unsupported FEC on device
-    uint32_t pad_;
-    uint32_t stamp[8];      // diagnostic builds (-DFX_STAMPS): shader-clock deltas of the decode phases
+struct FxPayResult {        // diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases
+    uint32_t stamp[8];
 };

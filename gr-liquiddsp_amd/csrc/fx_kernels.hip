@@ -83,10 +83,14 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
     return (int64_t)(((uint64_t)hi << 32) | lo);
 }
 
-// samples below `floor` (before the last synchroniser reset) and outside the stream read as zero
-__device__ __forceinline__ float2 xv(const float2 *x, int64_t p, int64_t floor_, int64_t n)
+// A stream as a kernel sees it: the block's new samples at logical indices [0, n), the tail carried over from the
+// previous block right-aligned below 0 (index p < 0 reads xa_end[p]).  Samples below `floor` (before the last
+// synchroniser reset) and beyond the data read as zero; a floor is never below the start of the carried tail.
+struct XSrc { const float2 *x, *xa_end; int64_t n; };
+__device__ __forceinline__ float2 xld(const XSrc &s, int64_t p) { return p < 0 ? s.xa_end[p] : s.x[p]; }
+__device__ __forceinline__ float2 xv(const XSrc &s, int64_t p, int64_t floor_)
 {
-    return (p >= floor_ && p >= 0 && p < n) ? x[p] : make_float2(0.0f, 0.0f);
+    return (p >= floor_ && p < s.n && (p >= 0 || s.xa_end)) ? xld(s, p) : make_float2(0.0f, 0.0f);
 }
 
 // One hop of the exact detector (qdetector SEEK): L.win holds the 512-sample window (overlap half + new half,
@@ -226,32 +230,62 @@ template <class LDS> __device__ __forceinline__ void decode_header_bytes(LDS &L,
 #ifndef FX_FLEX_OCC
 #define FX_FLEX_OCC 2        // same for the flex_rx instance
 #endif
+// One walk: the synchroniser's state machine from (start, floor, fresh) of `job` until the job's stop / hand-off / end of
+// data.  Called by the whole workgroup (fx_walk_kernel: once; fx_chain_kernel: for every repair).  L.S (template spectrum)
+// must be loaded; the result record and the frames go to global memory (thread 0), verification runs to `runs`.
 template <int MODE, int WW>
-__global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
-void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, const FxTables *T)
+__device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_index, FxWalkResult *result, FxFrame *frames, FxVerifyRun *runs,
+                                         uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, WalkLdsT<WW> &L,
+                                         const float2 (&twA)[7], const float2 (&twB)[7])
 {
     constexpr int WALK_WAVES = WW, WALK_THREADS = 64 * WW;
-    __shared__ WalkLdsT<WW> L;
-    const FxWalkJob job = jobs[blockIdx.x];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float2 *x = job.x;
+    const XSrc xs = { job.x, job.xa_end, job.n };
     const int64_t n = job.n;
-
-    float2 twA[7], twB[7];
-#pragma unroll
-    for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
-    for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
 
     int64_t pos = job.start, floor_ = job.floor;
     bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
     uint32_t nfr = 0, hops = 0, hops_cheap = 0, exact_left = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
     int64_t ho_start = 0, ho_pos = 0; int32_t ho_off = 0; float ho_rxy = 0.0f; uint32_t ho_clear = 0;
     float x2_0 = 0.0f;
+    if (job.state_in) {
+        // true walker of a continuing stream: the previous block's chain kernel left the resume state on the device
+        const FxStreamState st = *job.state_in;
+        if (st.invalid) {
+            if (tid == 0) {
+                FxWalkResult r; r.n_frames = 0; r.exit_code = FX_EXIT_INVALID; r.pos = 0; r.floor = 0; r.fresh = 1; r.has_handoff = 0;
+                r.handoff_start = 0; r.handoff_offset = 0; r.hops = 0; r.handoff_rxy = 0.0f; r.hops_cheap = 0; r.tail_pos = 0; r.tail_floor = 0;
+                r.handoff_pos = 0; r.handoff_clear = 0; r.tail_flags = FX_FLAG_SPAN_EXACT;
+                for (int i = 0; i < 4; i++) r.stamp[i] = 0;
+                *result = r;
+            }
+            return;
+        }
+        pos = st.pos; floor_ = st.floor; fresh = st.fresh != 0;
+    }
     // A locked flex_rx walker may skip hops its coarse scan finds empty (job.no_skip == 0): it stays on the true hop
-    // grid and runs the exact detector only around coarse-scan candidates; the host has every hop between
-    // span_pos and the next detection re-checked by fx_seekverify_kernel.
+    // grid and runs the exact detector only around coarse-scan candidates; every hop between span_pos and the next
+    // detection is re-checked by fx_seekverify_kernel (the walker emits the runs itself when the span closes).
     const bool may_skip = MODE == FX_MODE_FLEXRX && job.no_skip == 0;
     int64_t span_pos = pos, span_floor = floor_;
+    // the span is the chain's business only if the walker was locked when the seek began
+    uint32_t span_flags = (fresh ? FX_FLAG_SEEK_FRESH : 0u) | ((!may_skip || !locked) ? FX_FLAG_SPAN_EXACT : 0u);
+    auto emit_runs = [&](int64_t end, uint32_t owner) {          // thread 0: hops [span_pos, end) to the verifier
+        if (span_flags & FX_FLAG_SPAN_EXACT) return false;
+        const int64_t nh = (end - span_pos) / FX_HOP;
+        if (nh <= 0) return false;
+        const uint32_t per = job.verify_per ? job.verify_per : 4u;
+        const uint32_t nr = (uint32_t)((nh + per - 1) / per);
+        const uint32_t base = atomicAdd(&hdr->n_runs, nr);
+        atomicAdd(&hdr->verify_hops, (uint32_t)nh);
+        if ((uint64_t)base + nr > run_cap) return true;          // no room: the caller marks the span bad (walked again, exactly)
+        for (uint32_t r = 0; r < nr; r++) {
+            FxVerifyRun v; v.pos = span_pos + (int64_t)r * per * FX_HOP; v.floor = span_floor; v.job = job_index; v.owner = owner;
+            v.nhops = (uint32_t)min((int64_t)per, nh - (int64_t)r * per); v.pad_ = 0;
+            runs[base + r] = v;
+        }
+        return false;
+    };
 #ifdef FX_STAMPS
     unsigned long long wt_ = __builtin_readcyclecounter(); uint32_t wst_[4] = { 0, 0, 0, 0 };
 #define WSTAMP(i) do { unsigned long long t2_ = __builtin_readcyclecounter(); wst_[i] += (uint32_t)(t2_ - wt_); wt_ = t2_; } while (0)
@@ -262,8 +296,9 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
     const float2 *sc = T->sc;
 
     const bool lo = tid < HALF;            // threads that own one sample of a 256-sample half
+    __syncthreads();
     if (fresh) { if (lo) L.win[tid] = make_float2(0.0f, 0.0f); }
-    else { float2 w = lo ? xv(x, pos - FX_HOP + tid, floor_, n) : make_float2(0.0f, 0.0f); if (lo) L.win[tid] = w; x2_0 = block_sum256(cm2(w), L, lane, wave); }
+    else { float2 w = lo ? xv(xs, pos - FX_HOP + tid, floor_) : make_float2(0.0f, 0.0f); if (lo) L.win[tid] = w; x2_0 = block_sum256(cm2(w), L, lane, wave); }
     __syncthreads();
 
     for (;;) {
@@ -284,7 +319,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         if ((!locked || may_skip) && MODE == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n &&
             (in_handoff || pos + (WALK_WAVES - 1) * FX_HOP < job.stop)) {
             __syncthreads();
-            for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(x, pos - FX_HOP + i, floor_, n);
+            for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(xs, pos - FX_HOP + i, floor_);
             __syncthreads();
             hops_cheap += WALK_WAVES;
             {
@@ -350,7 +385,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             continue;
         }
 
-        float2 nw = lo ? xv(x, pos + tid, floor_, n) : make_float2(0.0f, 0.0f);
+        float2 nw = lo ? xv(xs, pos + tid, floor_) : make_float2(0.0f, 0.0f);
         if (lo) L.win[FX_HOP + tid] = nw;
 
         // ------------------------------------------------------------ pre-lock coarse scan (speculative walkers only)
@@ -436,7 +471,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
 
         // ------------------------------------------------------------ ALIGN on x[a0, a0+512)
         __syncthreads();
-        for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.win[i] = xv(x, a0 + i, floor_, n);
+        for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.win[i] = xv(xs, a0 + i, floor_);
         __syncthreads();
         if (wave == 0) {
             float2 a[8];
@@ -518,7 +553,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
         fr.seek_pos = span_pos; fr.seek_floor = span_floor; fr.det_pos = pos;
         fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
-        fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f; fr.flags = floor_ <= a0 ? FX_FLAG_FLOOR_CLEAR : 0u;
+        fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f; fr.flags = (floor_ <= a0 ? FX_FLAG_FLOOR_CLEAR : 0u) | span_flags;
         fr.pay_len = fr.ms = fr.check = fr.fec0 = fr.fec1 = fr.pay_sym_len = 0;
 #pragma unroll
         for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = 0;
@@ -538,6 +573,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
             fr.next = a0 + FX_NFFT;
             if (tid == 0) frames[job.frame_base + nfr] = fr;
             nfr++;
+            span_pos = a0 + FX_NFFT; span_floor = floor_; span_flags = FX_FLAG_SPAN_EXACT;
             __syncthreads();
             float2 w = lo ? L.win[FX_HOP + tid] : make_float2(0.0f, 0.0f);
             __syncthreads();
@@ -555,7 +591,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         const int nh = (int)sym_sample(FX_SYM0_PAY - 1, fr.mfc0);      // sample of the last header symbol
         if (a0 + nh + 1 > n) { exit_code = FX_EXIT_NEED_DATA; break; }
         for (int m = tid; m <= nh; m += WALK_THREADS)
-            L.v[m] = derot(xv(x, a0 + m, floor_, n), fr.mix_th + mix_dl * (uint32_t)m, sc);
+            L.v[m] = derot(xv(xs, a0 + m, floor_), fr.mix_th + mix_dl * (uint32_t)m, sc);
         if (tid < FX_MF_TAPS) L.taps[tid] = T->proto[fr.pfb + FX_NPFB * tid];
         __syncthreads();
         if (tid < FX_HDR_SYM) {
@@ -662,12 +698,15 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         locked = true; fr.flags |= FX_FLAG_EXACT;
         bool incomplete = fr.next > n;
         if (incomplete) fr.flags |= FX_FLAG_INCOMPLETE;
-        if (tid == 0) frames[job.frame_base + nfr] = fr;
+        if (tid == 0) {
+            if (!incomplete && emit_runs(fr.det_pos, job.frame_base + nfr)) fr.flags |= FX_FLAG_SPAN_BAD;
+            frames[job.frame_base + nfr] = fr;
+        }
         nfr++;
         if (incomplete) { exit_code = FX_EXIT_PAYLOAD; break; }
         // synchroniser reset: fresh detector right after the frame's last symbol
         pos = fr.next; floor_ = fr.next; fresh = true; x2_0 = 0.0f;
-        span_pos = pos; span_floor = floor_;
+        span_pos = pos; span_floor = floor_; span_flags = FX_FLAG_SEEK_FRESH | (may_skip ? 0u : FX_FLAG_SPAN_EXACT);
         __syncthreads();
         if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
         __syncthreads();
@@ -678,35 +717,60 @@ void fx_walk_kernel(const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frame
         r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
         r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
         r.handoff_rxy = ho_rxy; r.hops_cheap = hops_cheap;
-        r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos; r.handoff_clear = ho_clear; r.pad_ = 0;
+        r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos; r.handoff_clear = ho_clear;
+        // the seek in progress: a frame cut short by the end of data is walked again by the next block, from this very state
+        r.tail_flags = span_flags;
+        if (emit_runs(has_handoff ? ho_pos : pos, 0x80000000u | job_index)) r.tail_flags |= FX_FLAG_SPAN_BAD;
 #ifdef FX_STAMPS
         for (int i = 0; i < 4; i++) r.stamp[i] = wst_[i];
 #else
         for (int i = 0; i < 4; i++) r.stamp[i] = 0;
 #endif
-        results[blockIdx.x] = r;
+        *result = r;
+        atomicAdd(&hdr->hops, hops); atomicAdd(&hdr->hops_cheap, hops_cheap); atomicAdd(&hdr->walk_jobs_run, 1u);
     }
 }
 
-extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, FxWalkResult *results,
-                                     FxFrame *frames, const FxTables *T)
+template <int MODE, int WW>
+__global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
+void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
+                    FxBlockHdr *hdr, const FxTables *T)
 {
-    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_DETECT, FX_DETECT_WAVES>), dim3(njobs), dim3(64 * FX_DETECT_WAVES), 0, st, jobs, results, frames, T);
-    else hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, results, frames, T);
+    __shared__ WalkLdsT<WW> L;
+    const uint32_t ji = job_list[blockIdx.x];
+    const FxWalkJob job = jobs[ji];
+    const int tid = threadIdx.x, lane = tid & 63;
+    float2 twA[7], twB[7];
+#pragma unroll
+    for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
+    for (int i = tid; i < FX_NFFT; i += 64 * WW) L.S[i] = T->S[i];
+    walk_run<MODE, WW>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB);
+}
+
+extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
+                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T)
+{
+    if (njobs == 0) return hipSuccess;
+    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_DETECT, FX_DETECT_WAVES>), dim3(njobs), dim3(64 * FX_DETECT_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
+    else hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
     return hipGetLastError();
 }
 
 // ===================================================================== seek verification
 // A run of consecutive hops of the exact detector, all expected to come up empty (the hops a locked walker skipped
-// on the strength of its coarse scan).  Hops are independent given (pos, floor), so the runs are cut to spread over
-// the whole chip; the workgroup slides its window exactly like the walker does.
+// on the strength of its coarse scan).  Hops are independent given (pos, floor), so the runs -- emitted by the walkers
+// themselves, counted in the block header -- spread over the whole chip; a workgroup takes runs grid-stride and slides its
+// window exactly like the walker does.  A hop that does fire marks the span's owner (a frame-table slot, or a job's
+// tail span) FX_FLAG_SPAN_BAD; fx_chain_kernel then walks that span again with the exact detector on every hop.
 template <int WW>
 __global__ __launch_bounds__(64 * WW, FX_DETECT_OCC)
-void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
+void fx_seekverify_kernel(const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, FxBlockHdr *hdr,
+                          const FxTables *T)
 {
     constexpr int WALK_THREADS = 64 * WW;
     __shared__ SeekLdsT<WW> L;
-    const FxVerifyJob job = jobs[blockIdx.x];
+    const uint32_t nruns = min(hdr->n_runs, run_cap);
+    if (blockIdx.x >= nruns) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 twA[7], twB[7];
 #pragma unroll
@@ -714,31 +778,449 @@ void fx_seekverify_kernel(const FxVerifyJob *jobs, FxVerifyResult *results, cons
     for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
     const float s2sum = T->s2sum;
     const bool lo = tid < HALF;
-    int64_t pos = job.pos;
-    float2 w = lo ? xv(job.x, pos - FX_HOP + tid, job.floor, job.n) : make_float2(0.0f, 0.0f);
-    if (lo) L.win[tid] = w;
-    float x2_0 = block_sum256(cm2(w), L, lane, wave);
-    FxVerifyResult r; r.det_hop = 0xFFFFFFFFu; r.bidx = 0; r.boff = 0; r.peak = 0.0f;
-    for (uint32_t h = 0; h < job.nhops; h++) {
-        const float2 nw = lo ? xv(job.x, pos + tid, job.floor, job.n) : make_float2(0.0f, 0.0f);
-        if (lo) L.win[FX_HOP + tid] = nw;
-        const float x2_1 = block_sum256(cm2(nw), L, lane, wave);
-        uint32_t bidx; int boff; float peak;
-        if (seek_sweep(L, x2_0, x2_1, job.threshold, s2sum, twA, twB, lane, wave, bidx, boff, peak)) {
-            r.det_hop = h; r.bidx = bidx; r.boff = boff; r.peak = peak;
-            break;
+    for (uint32_t ri = blockIdx.x; ri < nruns; ri += gridDim.x) {
+        const FxVerifyRun run = runs[ri];
+        const FxWalkJob &jb = jobs[run.job];
+        const XSrc xs = { jb.x, jb.xa_end, jb.n };
+        const float threshold = jb.threshold;
+        int64_t pos = run.pos;
+        __syncthreads();
+        float2 w = lo ? xv(xs, pos - FX_HOP + tid, run.floor) : make_float2(0.0f, 0.0f);
+        if (lo) L.win[tid] = w;
+        float x2_0 = block_sum256(cm2(w), L, lane, wave);
+        bool fired = false;
+        for (uint32_t h = 0; h < run.nhops; h++) {
+            const float2 nw = lo ? xv(xs, pos + tid, run.floor) : make_float2(0.0f, 0.0f);
+            if (lo) L.win[FX_HOP + tid] = nw;
+            const float x2_1 = block_sum256(cm2(nw), L, lane, wave);
+            uint32_t bidx; int boff; float peak;
+            if (seek_sweep(L, x2_0, x2_1, threshold, s2sum, twA, twB, lane, wave, bidx, boff, peak)) { fired = true; break; }
+            __syncthreads();
+            if (lo) L.win[tid] = nw;
+            x2_0 = x2_1; pos += FX_HOP;
+            __syncthreads();
         }
-        __syncthreads();
-        if (lo) L.win[tid] = nw;
-        x2_0 = x2_1; pos += FX_HOP;
-        __syncthreads();
+        if (fired && tid == 0) {
+            if (run.owner & 0x80000000u) atomicOr(&results[run.owner & 0x7fffffffu].tail_flags, (uint32_t)FX_FLAG_SPAN_BAD);
+            else atomicOr(&frames[run.owner].flags, (uint32_t)FX_FLAG_SPAN_BAD);
+            atomicAdd(&hdr->verify_failures, 1u);
+        }
     }
-    if (tid == 0) results[blockIdx.x] = r;
 }
 
-extern "C" hipError_t fx_launch_seekverify(unsigned njobs, hipStream_t st, const FxVerifyJob *jobs, FxVerifyResult *results, const FxTables *T)
+extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results,
+                                           FxFrame *frames, FxBlockHdr *hdr, const FxTables *T)
 {
-    hipLaunchKernelGGL(fx_seekverify_kernel<FX_VERIFY_WAVES>, dim3(njobs), dim3(64 * FX_VERIFY_WAVES), 0, st, jobs, results, T);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(fx_seekverify_kernel<FX_VERIFY_WAVES>, dim3(grid), dim3(64 * FX_VERIFY_WAVES), 0, st, runs, run_cap, jobs, results, frames, hdr, T);
+    return hipGetLastError();
+}
+
+// ===================================================================== chain: stitch, repair, resume state, carried tail
+// One workgroup per stream turns the walkers' lists into the list the sequential synchroniser would have produced
+// (DESIGN.md section 2.1), entirely on the device:
+//   * a segment's walker ends with its hand-off target (start, CFO bin); if the next segment's speculative list holds
+//     that very frame (and no zero-floor masked what either of them read), the lists are spliced there;
+//   * otherwise -- and wherever fx_seekverify_kernel found the exact detector firing on a hop a walker had skipped, or a
+//     frame table filled up -- this workgroup walks the stretch itself, from the true state, exact detector on every hop
+//     (walk_run: it IS a walker), and carries on from that walk's result;
+//   * the chain's frames go, compacted, to the stream's region of the chain table; the resume state and the unconsumed
+//     tail go to where the next block's true walker will look for them.
+// Fast path (no repair needed anywhere, at most CHAIN_MAXJ segments): hand-off look-ups for all segments in parallel,
+// a pointer chase through LDS, parallel compaction.  Anything else takes the general sequential loop below it.
+#define CHAIN_MAXJ 2048
+#define CHAIN_NONE 1023u
+
+__device__ __forceinline__ void wg_sync_global() { __threadfence(); __syncthreads(); __threadfence(); }
+
+__device__ __forceinline__ void copy_frame(FxFrame *dst, const FxFrame *src)
+{
+    const uint2 *a = reinterpret_cast<const uint2 *>(src); uint2 *b = reinterpret_cast<uint2 *>(dst);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(FxFrame) / 8); i++) b[i] = a[i];
+}
+
+template <int MODE, int WW>
+__global__ __launch_bounds__(64 * WW, 1)
+void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total, FxWalkResult *results, FxFrame *frames,
+                     FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, uint32_t force_slow,
+                     const FxTables *T)
+{
+    constexpr int NT = 64 * WW;
+    __shared__ WalkLdsT<WW> L;
+    __shared__ uint32_t c_lk[CHAIN_MAXJ], c_info[CHAIN_MAXJ], c_base[CHAIN_MAXJ];
+    __shared__ float c_rxy[CHAIN_MAXJ];
+    __shared__ uint16_t c_m[CHAIN_MAXJ], c_pred[CHAIN_MAXJ];
+    __shared__ uint32_t c_sh[8];
+    const uint32_t s = blockIdx.x;
+    const FxStreamDesc sd = streams[s];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const XSrc xs = { sd.x, sd.xa_end, sd.n };
+    FxFrame *out = chain + sd.chain_base;
+    FxStreamState st_in; st_in.pos = 0; st_in.floor = 0; st_in.carry_len = 0; st_in.fresh = 1; st_in.invalid = 0; st_in.overflow = 0; st_in.pad_ = 0;
+    if (sd.state_in) st_in = *sd.state_in;
+    if (st_in.invalid) {                                     // nothing to build on: say so downstream, the host replays
+        if (tid == 0) {
+            FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
+            *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
+            atomicOr(&hdr->flags, (uint32_t)FX_BLK_INVALID);
+        }
+        return;
+    }
+    float2 twA[7], twB[7];
+#pragma unroll
+    for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
+    for (int i = tid; i < FX_NFFT; i += NT) L.S[i] = T->S[i];
+
+    const uint32_t first = sd.first_job, nj = sd.n_jobs, end = first + nj;
+    uint32_t cnt = 0;
+    int64_t fin_pos = 0, fin_floor = 0; bool fin_fresh = true;
+    bool done = false;
+
+    // ------------------------------------------------------------------------------------------ fast path
+    if (!force_slow && nj <= CHAIN_MAXJ) {
+        // A. every segment: its own summary and the look-up of its hand-off target in the list it points at
+        for (uint32_t j = tid; j < nj; j += NT) {
+            const FxWalkResult &R = results[first + j];
+            const FxFrame *F = frames + jobs[first + j].frame_base;
+            uint32_t nf = R.n_frames; const uint32_t ex = R.exit_code;
+            if (ex == FX_EXIT_PAYLOAD && nf > 0) nf--;
+            uint32_t cntE = 0;
+            for (uint32_t i = 0; i < nf; i++) cntE += (F[i].flags & FX_FLAG_EXACT) ? 1u : 0u;
+            c_info[j] = nf | (cntE << 10) | (ex << 20) | ((R.has_handoff ? 1u : 0u) << 23) | (((R.tail_flags & FX_FLAG_SPAN_BAD) ? 1u : 0u) << 24);
+            c_rxy[j] = R.handoff_rxy;
+            uint32_t lk = CHAIN_NONE << 11;
+            if (R.has_handoff && ex == FX_EXIT_STOP && j + 1 < nj) {
+                uint32_t nxt = j + 1;
+                while (nxt + 1 < nj && R.handoff_start >= jobs[first + nxt].stop + FX_HOP) nxt++;
+                const FxWalkResult &RN = results[first + nxt]; const FxFrame *FN = frames + jobs[first + nxt].frame_base;
+                uint32_t found = CHAIN_NONE, skipE = 0, eb = 0;
+                uint32_t nfn = RN.n_frames, nfe = nfn; if (RN.exit_code == FX_EXIT_PAYLOAD && nfe > 0) nfe--;
+                for (uint32_t i = 0; R.handoff_clear && i < nfn && i < CHAIN_NONE; i++) {
+                    const uint32_t fl = FN[i].flags;
+                    if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; skipE = eb; break; }
+                    if ((fl & FX_FLAG_EXACT) && i < nfe) eb++;
+                }
+                lk = nxt | (found << 11) | (skipE << 21);
+            }
+            c_lk[j] = lk; c_m[j] = 0xFFFFu;
+        }
+        __syncthreads();
+        // B. the chain itself: a pointer chase through LDS
+        if (tid == 0) {
+            uint32_t cur = 0, m = 0, base = 0, skipE = 0, pred = 0xFFFFu, problem = 0, endjob = 0, end_nothing = 0;
+            bool spliced = false;
+            for (;;) {
+                const uint32_t inf = c_info[cur], nf = inf & 1023u, cntE = (inf >> 10) & 1023u, ex = (inf >> 20) & 7u;
+                c_m[cur] = (uint16_t)(m | (spliced ? 0x8000u : 0u)); c_base[cur] = base; c_pred[cur] = (uint16_t)pred;
+                base += cntE - skipE;
+                const bool nothing = spliced && nf <= m;
+                if (!nothing && ((inf >> 24) & 1u)) { problem = 1; break; }            // a skipped hop of its tail seek fires
+                if (ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID) { problem = 1; break; }
+                if (cur + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 23) & 1u)) { endjob = cur; end_nothing = nothing ? 1u : 0u; break; }
+                const uint32_t lk = c_lk[cur], found = (lk >> 11) & 1023u;
+                if (found == CHAIN_NONE) { problem = 1; break; }                        // target not in the next list: repair
+                pred = cur; spliced = true; m = found; skipE = lk >> 21; cur = lk & 2047u;
+            }
+            c_sh[0] = problem; c_sh[1] = endjob; c_sh[2] = end_nothing; c_sh[3] = base;
+            if (base > sd.chain_cap) c_sh[0] = 1;
+        }
+        __syncthreads();
+        // C. compaction, one thread per segment on the chain
+        if (!c_sh[0]) {
+            for (uint32_t j = tid; j < nj; j += NT) {
+                const uint32_t cm = c_m[j];
+                if (cm == 0xFFFFu) continue;
+                const uint32_t m = cm & 0x7FFFu, nf = c_info[j] & 1023u; const bool spliced = (cm & 0x8000u) != 0;
+                const FxFrame *F = frames + jobs[first + j].frame_base;
+                uint32_t o = c_base[j];
+                for (uint32_t i = m; i < nf; i++) {
+                    const uint32_t fl = F[i].flags;
+                    if (!(fl & FX_FLAG_EXACT)) continue;
+                    const bool own = !(spliced && i == m);
+                    if (own && (fl & FX_FLAG_SPAN_BAD)) c_sh[0] = 1;
+                    copy_frame(out + o, F + i);
+                    if (!own) out[o].rxy = c_rxy[c_pred[j]];                            // coarse peak as the true chain saw it
+                    o++;
+                }
+            }
+        }
+        __syncthreads();
+        if (!c_sh[0]) {
+            const uint32_t ej = c_sh[1];
+            const FxWalkResult &R = c_sh[2] ? results[first + c_pred[ej]] : results[first + ej];
+            fin_pos = R.pos; fin_floor = R.floor; fin_fresh = R.fresh != 0; cnt = c_sh[3];
+            done = true;
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------------------------------ general path
+    if (!done) {
+        uint32_t cur = first, m = 0;
+        const FxWalkResult *Rp = results + cur; const FxFrame *F = frames + jobs[cur].frame_base;
+        FxWalkResult *rep_res = results + n_jobs_total + s;
+        float splice_rxy = -1.0f; bool spliced = false;
+        int64_t tpos = 0, tfloor = 0; bool tfresh = true;
+        cnt = 0;
+        // a walk this workgroup does itself (one call site: the walker is a big piece of code)
+        bool need_walk = false; uint32_t wj = 0; int64_t wst = 0, wfl = 0; bool wfr = false;
+        auto repair = [&](uint32_t jidx, int64_t st, int64_t fl, bool fr) { need_walk = true; wj = jidx; wst = st; wfl = fl; wfr = fr; };
+        for (;;) {
+            if (need_walk) {
+                FxWalkJob j = jobs[wj];
+                j.start = wst; j.floor = wfl; j.fresh = wfr ? 1u : 0u; j.prelock = 0; j.no_skip = 1; j.state_in = nullptr;
+                j.frame_base = sd.repair_base; j.max_frames = sd.repair_cap;
+                __syncthreads();
+                walk_run<MODE, WW>(j, wj, rep_res, frames, runs, run_cap, hdr, T, L, twA, twB);
+                wg_sync_global();
+                if (tid == 0) atomicAdd(&hdr->repairs, 1u);
+                Rp = rep_res; F = frames + sd.repair_base; m = 0; need_walk = false;
+            }
+            const FxWalkResult R = *Rp;
+            uint32_t nf = R.n_frames;
+            if (R.exit_code == FX_EXIT_PAYLOAD && nf > 0) nf--;            // incomplete frame: the next block takes it
+            int bad = -1;
+            for (uint32_t i = m; i < nf; i++) {
+                const uint32_t fl = F[i].flags;
+                if (!(fl & FX_FLAG_EXACT)) continue;                       // tentative pre-lock entries of a speculative walk
+                const bool own = !(i == m && splice_rxy >= 0.0f);          // (a spliced frame's seek is the hand-off's)
+                if (own && (fl & FX_FLAG_SPAN_BAD)) { bad = (int)i; break; }
+                if (cnt < sd.chain_cap) {
+                    const uint32_t *a = reinterpret_cast<const uint32_t *>(F + i); uint32_t *b = reinterpret_cast<uint32_t *>(out + cnt);
+                    if (tid < (int)(sizeof(FxFrame) / 4))               // coarse peak of a spliced frame: as the true chain saw it
+                        b[tid] = (!own && tid == (int)(offsetof(FxFrame, rxy) / 4)) ? __builtin_bit_cast(uint32_t, splice_rxy) : a[tid];
+                }
+                cnt++;
+            }
+            if (bad >= 0) {                                                // a skipped hop of that frame's seek fires: walk it exactly
+                const int64_t sp = F[bad].seek_pos, sf = F[bad].seek_floor; const bool sfr = (F[bad].flags & FX_FLAG_SEEK_FRESH) != 0;
+                repair(cur, sp, sf, sfr); spliced = false; splice_rxy = -1.0f; continue;
+            }
+            // the seek in progress when this walker stopped (a spliced-in walker that contributed nothing is not on the chain)
+            if (!(spliced && nf <= m) && (R.tail_flags & FX_FLAG_SPAN_BAD)) {
+                repair(cur, R.tail_pos, R.tail_floor, (R.tail_flags & FX_FLAG_SEEK_FRESH) != 0); spliced = false; splice_rxy = -1.0f; continue;
+            }
+            splice_rxy = -1.0f;
+            const bool last = (cur + 1 == end);
+            if (R.exit_code == FX_EXIT_TABLE_FULL) { repair(cur, R.pos, R.floor, R.fresh != 0); spliced = false; continue; }   // same segment, where the table filled up
+            if (last || R.exit_code != FX_EXIT_STOP || !R.has_handoff) {
+                if (spliced && nf <= m) { fin_pos = tpos; fin_floor = tfloor; fin_fresh = tfresh; }   // its own hop state is speculative: resume from the true chain's hand-off hop
+                else { fin_pos = R.pos; fin_floor = R.floor; fin_fresh = R.fresh != 0; }
+                break;
+            }
+            spliced = false;
+            // hand-off: look the target up in the next segment's speculative list
+            // (segments the true walker crossed without a detection cannot hold the target: skip them)
+            uint32_t nxt = cur + 1;
+            while (nxt + 1 < end && R.handoff_start >= jobs[nxt].stop + FX_HOP) nxt++;
+            const FxWalkResult *RNp = results + nxt; const FxFrame *FN = frames + jobs[nxt].frame_base;
+            const uint32_t nfn = RNp->n_frames;
+            uint32_t found = 0xFFFFFFFFu;
+            // A frame is a function of (start, CFO bin) alone only if no sample it reads was masked by a zero-floor: splice
+            // only when both floors lie at or below the start; else walk the segment from the true state.
+            for (uint32_t i = 0; R.handoff_clear && i < nfn; i++) {
+                const uint32_t fl = FN[i].flags;
+                if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; break; }
+            }
+            if (found != 0xFFFFFFFFu) {
+                splice_rxy = R.handoff_rxy; spliced = true; tpos = R.pos; tfloor = R.floor; tfresh = R.fresh != 0;
+                cur = nxt; m = found; Rp = RNp; F = FN; continue;
+            }
+            repair(nxt, R.pos, R.floor, R.fresh != 0);
+            cur = nxt;
+        }
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------------------------------ resume state and tail
+    if (cnt > sd.chain_cap) { if (tid == 0) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CHAIN_FULL); cnt = sd.chain_cap; }
+    int64_t keep_from = fin_fresh ? fin_pos : fin_pos - FX_HOP;
+    keep_from = max(-st_in.carry_len, min(keep_from, sd.n));
+    const int64_t keep = sd.n - keep_from;
+    const bool overflow = keep > sd.carry_cap;
+    if (!overflow)
+        for (int64_t i = tid; i < keep; i += NT) sd.carry_out_end[i - keep] = xld(xs, keep_from + i);
+    if (tid == 0) {
+        FxStreamState so;
+        so.pos = fin_pos - sd.n; so.floor = max(fin_floor - sd.n, -keep); so.carry_len = keep; so.fresh = fin_fresh ? 1u : 0u;
+        so.invalid = overflow ? 1u : 0u; so.overflow = overflow ? 1u : 0u; so.pad_ = 0;
+        *sd.state_out = so; *sd.state_out_host = so;
+        chain_count[s] = cnt;
+        if (overflow) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CARRY_OVERFLOW);
+    }
+}
+
+extern "C" hipError_t fx_launch_chain(unsigned mode, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
+                                      FxWalkResult *results, FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap,
+                                      FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T)
+{
+    if (mode == FX_MODE_DETECT)
+        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_DETECT, FX_DETECT_WAVES>), dim3(nstreams), dim3(64 * FX_DETECT_WAVES), 0, st, streams, jobs, n_jobs_total, results,
+                           frames, chain, chain_count, runs, run_cap, hdr, force_slow, T);
+    else
+        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES>), dim3(nstreams), dim3(64 * FX_FLEX_WAVES), 0, st, streams, jobs, n_jobs_total, results,
+                           frames, chain, chain_count, runs, run_cap, hdr, force_slow, T);
+    return hipGetLastError();
+}
+
+// ===================================================================== plan: chain frames -> payload jobs, work lists, result records
+// One workgroup lays the payload stage out on the device: arena offsets by prefix sums over the chain frames of all streams
+// (stream order, then position -- the order results are reported in), the matched-filter work items, the PLL lists (one per
+// modulation class, each padded to whole waves) and the two decode lists (with / without a Reed-Solomon stage).  It also
+// writes one FxOutRec per frame straight into pinned host memory and mirrors the block header there.
+#define PLAN_THREADS 1024
+
+__device__ __forceinline__ unsigned pll_class(unsigned ms)
+{
+    switch (ms) {
+    case FX_MODEM_PSK2: return 0; case FX_MODEM_PSK4: return 1; case FX_MODEM_PSK8: return 2; case FX_MODEM_PSK16: return 3;
+    case FX_MODEM_DPSK2: return 4; case FX_MODEM_DPSK4: return 5; case FX_MODEM_DPSK8: return 6; case FX_MODEM_ASK4: return 7;
+    case FX_MODEM_QAM16: return 8; case FX_MODEM_QAM32: return 9; case FX_MODEM_QAM64: return 10; default: return 11;   // QPSK
+    }
+}
+
+// exclusive scan of one value per thread over the workgroup (PLAN_THREADS threads); returns the prefix, `total` on all threads
+__device__ __forceinline__ uint32_t plan_scan(uint32_t v, uint32_t *ws, uint32_t &total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
+    __syncthreads();
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    uint32_t wb = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < PLAN_THREADS / 64; w++) { const uint32_t t = ws[w]; if (w < wave) wb += t; tot += t; }
+    total = tot;
+    return wb + inc - v;
+}
+
+extern "C" __global__ __launch_bounds__(PLAN_THREADS)
+void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
+                    uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
+                    uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_host)
+{
+    __shared__ uint32_t ws[PLAN_THREADS / 64];
+    __shared__ uint32_t cls_cnt[FX_PLL_CLASSES], cls_base[FX_PLL_CLASSES + 1], cls_fill[FX_PLL_CLASSES], dec_cnt[2], dec_fill[2];
+    const int tid = threadIdx.x;
+    if (tid < FX_PLL_CLASSES) { cls_cnt[tid] = 0; cls_fill[tid] = 0; }
+    if (tid < 2) { dec_cnt[tid] = 0; dec_fill[tid] = 0; }
+    // 1. frames before each stream
+    uint32_t run = 0;
+    for (uint32_t s0 = 0; s0 < nstreams; s0 += PLAN_THREADS) {
+        const uint32_t sidx = s0 + tid;
+        const uint32_t c = sidx < nstreams ? chain_count[sidx] : 0u;
+        uint32_t tot; const uint32_t pre = plan_scan(c, ws, tot);
+        if (sidx < nstreams) stream_base[sidx] = run + pre;
+        run += tot;
+    }
+    const uint32_t N = run;
+    if (tid == 0) stream_base[nstreams] = N;
+    __threadfence(); __syncthreads(); __threadfence();
+    // 2. sizes, offsets, jobs, records, matched-filter items
+    uint32_t sym_run = 0, byte_run = 0, dw_run = 0, out_run = 0, mf_run = 0, npj = 0;
+    for (uint32_t g0 = 0; g0 < N; g0 += PLAN_THREADS) {
+        const uint32_t g = g0 + tid;
+        const bool live = g < N;
+        FxFrame f; uint32_t sidx = 0;
+        uint32_t sym_sz = 0, byte_sz = 0, dw_sz = 0, out_sz = 0, nblk = 0, bps = 0, k = 0, l0 = 0, l1 = 0;
+        bool valid = false;
+        if (live) {
+            uint32_t lo = 0, hi = nstreams;                                  // stream_base[lo] <= g < stream_base[hi]
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (stream_base[mid] <= g) lo = mid; else hi = mid; }
+            sidx = lo;
+            f = chain[streams[sidx].chain_base + (g - stream_base[sidx])];
+            valid = !detect && (f.flags & FX_FLAG_HEADER_VALID);
+            if (valid) {
+                bps = modem_bps(f.ms);
+                k = f.pay_len + crc_len(f.check); l0 = fec_enc_len(f.fec0, k); l1 = fec_enc_len(f.fec1, l0);
+                sym_sz = (f.pay_sym_len + 7u) & ~7u;                         // 8-symbol granules: 64-byte block I/O in the PLL kernel
+                byte_sz = (max(l1, k) + 8u + 15u) & ~15u;
+                dw_sz = ((8u * max(l0, k) + 6u + 63u) & ~63u) + 64u;          // whole 64-step chunks, lane-major
+                out_sz = (f.pay_len + 15u) & ~15u;
+                nblk = (f.pay_sym_len + 1023u) / 1024u;
+            }
+        }
+        uint32_t t0, t1, t2, t3, t4, t5;
+        const uint32_t sym_off = sym_run + plan_scan(sym_sz, ws, t0);
+        const uint32_t byte_off = byte_run + plan_scan(byte_sz, ws, t1);
+        const uint32_t dw_off = dw_run + plan_scan(dw_sz, ws, t2);
+        const uint32_t out_off = out_run + plan_scan(out_sz, ws, t3);
+        const uint32_t mf_off = mf_run + plan_scan(nblk, ws, t4);
+        (void)plan_scan(valid ? 1u : 0u, ws, t5);
+        sym_run += t0; byte_run += t1; dw_run += t2; out_run += t3; mf_run += t4; npj += t5;
+        if (live) {
+            const FxStreamDesc &sd = streams[sidx];
+            FxPayJob j;
+            j.x = sd.x; j.xa_end = sd.xa_end; j.start = f.start; j.mix_th = f.mix_th; j.mix_dl = f.mix_dl; j.mf_scale = f.mf_scale;
+            j.pfb = f.pfb; j.mfc0 = f.mfc0; j.pll_th = f.pll_th; j.pll_f = f.pll_f; j.ms = f.ms; j.bps = bps;
+            j.nsym = valid ? f.pay_sym_len : 0u; j.sym_off = sym_off;
+            j.pay_len = f.pay_len; j.check = f.check; j.fec0 = f.fec0; j.fec1 = f.fec1; j.k = k; j.l0 = l0; j.l1 = l1;
+            j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = valid ? 1u : 0u;
+            pjobs[g] = j;
+            FxOutRec r;
+            r.start = sd.abs_base + f.start; r.stream = sidx; r.offset = f.offset;
+            r.rxy = f.rxy; r.tau = f.tau; r.gamma = f.gamma; r.dphi = f.dphi; r.phi = f.phi; r.pfb = f.pfb;
+            r.pilot_dphi = f.pilot_dphi; r.pilot_phi = f.pilot_phi; r.pilot_gain = f.pilot_gain;
+            r.flags = f.flags & FX_FLAG_HEADER_VALID;
+            r.pay_len = valid ? f.pay_len : 0u; r.ms = f.ms; r.check = f.check; r.fec0 = f.fec0; r.fec1 = f.fec1;
+            r.nsym = valid ? f.pay_sym_len : 0u; r.bps = bps; r.sym_off = sym_off; r.out_off = out_off;
+            r.evm_sum = 0.0f; r.payload_valid = 0; r.status = 0;
+#pragma unroll
+            for (int i = 0; i < FX_HDR_DEC; i++) r.header[i] = f.header[i];
+            r.pad_[0] = 0;
+            recs[g] = r;
+            if (valid) {
+                for (uint32_t c = 0; c < nblk; c++) if (mf_off + c < mf_cap) { mf_job[mf_off + c] = g; mf_c0[mf_off + c] = c * 1024u; }
+                atomicAdd(&cls_cnt[pll_class(f.ms)], 1u);
+                atomicAdd(&dec_cnt[(f.fec0 == FX_FEC_RS_M8 || f.fec1 == FX_FEC_RS_M8) ? 1 : 0], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    // 3. PLL lists (one per modulation class, padded to whole waves) and decode lists
+    if (tid == 0) {
+        uint32_t b = 0;
+        for (int c = 0; c < FX_PLL_CLASSES; c++) { cls_base[c] = b; b += (cls_cnt[c] + 63u) & ~63u; }
+        cls_base[FX_PLL_CLASSES] = b;
+    }
+    __syncthreads();
+    const uint32_t pll_slots = min(cls_base[FX_PLL_CLASSES], list_cap);
+    for (uint32_t i = tid; i < pll_slots; i += PLAN_THREADS) pll_list[i] = 0xFFFFFFFFu;
+    __threadfence(); __syncthreads(); __threadfence();
+    for (uint32_t g = tid; g < N; g += PLAN_THREADS) {
+        const FxPayJob &j = pjobs[g];
+        if (!j.pad_) continue;
+        const unsigned c = pll_class(j.ms);
+        const uint32_t pp = cls_base[c] + atomicAdd(&cls_fill[c], 1u);
+        if (pp < list_cap) pll_list[pp] = g;
+        const int rs = (j.fec0 == FX_FEC_RS_M8 || j.fec1 == FX_FEC_RS_M8) ? 1 : 0;
+        const uint32_t dp = atomicAdd(&dec_fill[rs], 1u);
+        if (dp < list_cap) dec_list[(size_t)rs * list_cap + dp] = g;
+    }
+    __syncthreads();
+    // 4. block header, device copy and host mirror
+    if (tid == 0) {
+        FxBlockHdr h = *hdr;
+        h.n_frames = N; h.n_pjobs = npj; h.n_mfblk = min(mf_run, mf_cap); h.n_dec_plain = dec_cnt[0]; h.n_dec_rs = dec_cnt[1];
+        for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = cls_cnt[c]; h.pll_base[c] = cls_base[c]; }
+        h.pll_base[FX_PLL_CLASSES] = cls_base[FX_PLL_CLASSES];
+        h.sym_total = sym_run; h.byte_total = byte_run; h.dw_total = dw_run; h.out_total = out_run;
+        h.done = 0;
+        *hdr = h;
+        h.done = 1;
+        *hdr_host = h;
+    }
+}
+
+extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
+                                     uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
+                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_host)
+{
+    hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0, mf_cap,
+                       pll_list, dec_list, list_cap, hdr, hdr_host);
     return hipGetLastError();
 }
 
@@ -747,36 +1229,50 @@ extern "C" hipError_t fx_launch_seekverify(unsigned njobs, hipStream_t st, const
 #define PMF_SYMS    1024          // symbols per workgroup
 #define PMF_SPAN    (2 * PMF_SYMS + FX_MF_TAPS)
 
+// Work items (frame, first symbol) come from fx_plan_kernel; their number is only known on the device, so the grid is
+// sized from the host's estimate and strides over the list.
 extern "C" __global__ __launch_bounds__(PMF_THREADS)
-void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, float2 *sym_raw, const FxTables *T)
+void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr, float2 *sym_raw, const FxTables *T)
 {
     __shared__ float2 v[PMF_SPAN + 4];
     __shared__ float taps[FX_MF_TAPS];
-    const FxPayJob job = jobs[blk_job[blockIdx.x]];
-    const uint32_t c0 = blk_c0[blockIdx.x];                    // first payload symbol of this block
-    const uint32_t ns = min((uint32_t)PMF_SYMS, job.nsym - c0);
+    const uint32_t nitems = hdr->n_mfblk;
     const int tid = threadIdx.x;
-    const int64_t nlo = sym_sample((int64_t)FX_SYM0_PAY + c0, job.mfc0) - (FX_MF_TAPS - 1);
-    const int64_t nhi = sym_sample((int64_t)FX_SYM0_PAY + c0 + ns - 1, job.mfc0);
-    const int span = (int)(nhi - nlo + 1);
-    const float2 *x = job.x + job.start;
     const float2 *sc = T->sc;
-    if (tid < FX_MF_TAPS) taps[tid] = T->proto[job.pfb + FX_NPFB * tid];
-    for (int m = tid; m < span; m += PMF_THREADS) {
-        const int64_t nn = nlo + m;
-        v[m] = derot(x[nn], job.mix_th + job.mix_dl * (uint32_t)nn, sc);
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
-        const int nc = (int)(sym_sample((int64_t)FX_SYM0_PAY + c0 + i, job.mfc0) - nlo);
-        float ar = 0.0f, ai = 0.0f;
-#pragma unroll 7
-        for (int t = 0; t < FX_MF_TAPS; t++) {
-            const float2 w = v[nc - t]; const float h = taps[t];
-            ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+    for (uint32_t bi = blockIdx.x; bi < nitems; bi += gridDim.x) {
+        const FxPayJob job = jobs[blk_job[bi]];
+        const uint32_t c0 = blk_c0[bi];                            // first payload symbol of this item
+        const uint32_t ns = min((uint32_t)PMF_SYMS, job.nsym - c0);
+        const int64_t nlo = sym_sample((int64_t)FX_SYM0_PAY + c0, job.mfc0) - (FX_MF_TAPS - 1);
+        const int64_t nhi = sym_sample((int64_t)FX_SYM0_PAY + c0 + ns - 1, job.mfc0);
+        const int span = (int)(nhi - nlo + 1);
+        const XSrc xs = { job.x, job.xa_end, 0 };
+        __syncthreads();
+        if (tid < FX_MF_TAPS) taps[tid] = T->proto[job.pfb + FX_NPFB * tid];
+        for (int m = tid; m < span; m += PMF_THREADS) {
+            const int64_t nn = nlo + m;
+            v[m] = derot(xld(xs, job.start + nn), job.mix_th + job.mix_dl * (uint32_t)nn, sc);
         }
-        sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
+        __syncthreads();
+        for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
+            const int nc = (int)(sym_sample((int64_t)FX_SYM0_PAY + c0 + i, job.mfc0) - nlo);
+            float ar = 0.0f, ai = 0.0f;
+#pragma unroll 7
+            for (int t = 0; t < FX_MF_TAPS; t++) {
+                const float2 w = v[nc - t]; const float h = taps[t];
+                ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+            }
+            sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
+        }
     }
+}
+
+extern "C" hipError_t fx_launch_paymf(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
+                                      float2 *sym_raw, const FxTables *T)
+{
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(fx_paymf_kernel, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, sym_raw, T);
+    return hipGetLastError();
 }
 
 // ===================================================================== payload: PLL + hard demod (lane per frame)
@@ -822,23 +1318,9 @@ __device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const fl
 }
 
 template <int MS>
-__global__ __launch_bounds__(PLL_THREADS * PLL_MAX_WAVES)
-void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, uint32_t wg_skip, const float2 *sym_raw,
-                      float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
+__device__ __forceinline__ void pll_frame(uint32_t f, const FxPayJob *jobs, const float2 *sc, const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs)
 {
-    // Workgroups are dealt to CUs in launch order from the same starting CU for every grid, so the few waves of
-    // two concurrent PLL grids (consecutive blocks in flight) would pile onto the same SIMDs.  Leading dummy
-    // workgroups shift this grid's real ones onto other CUs.
-    if (blockIdx.x < wg_skip) return;
-    // a frame's PLL is one long dependent chain: when it shares a SIMD with walker / decoder waves of other
-    // blocks in flight, let it win the issue arbitration
-    __builtin_amdgcn_s_setprio(3);
-    __shared__ float2 sc[1024];
-    for (int i = threadIdx.x; i < 1024; i += blockDim.x) sc[i] = T->sc[i];
-    __syncthreads();
-    const uint32_t li = (blockIdx.x - wg_skip) * blockDim.x + threadIdx.x;
-    if (li >= njobs) return;
-    const uint32_t f = job_idx[li];
+    if (f == 0xFFFFFFFFu) return;                                                  // padding of the class's last wave
     const FxPayJob job = jobs[f];
     const float4 *in = reinterpret_cast<const float4 *>(sym_raw + job.sym_off);      // sym_off is a multiple of 8
     float4 *out = reinterpret_cast<float4 *>(framesyms + job.sym_off);
@@ -876,23 +1358,49 @@ void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
-    res[f].evm_sum = evm;
+    recs[f].evm_sum = evm;                                                          // straight into the host's result record
 }
 
-// host-side launcher (lives here so that the template instantiations stay in this translation unit)
-extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_skip, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
-                                       const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxPayResult *res, const FxTables *T)
+// One kernel for all modulation schemes: fx_plan_kernel lists the frames per scheme, each list padded to whole waves, so
+// a wave runs exactly one instantiation of the loop (the demodulator is resolved at compile time, straight-line code).
+// The number of waves is only known on the device: the grid strides over them.
+__global__ __launch_bounds__(PLL_THREADS * PLL_MAX_WAVES)
+void fx_paypll_kernel(const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr, const float2 *sym_raw,
+                      float2 *framesyms, uint8_t *hard, FxOutRec *recs, const FxTables *T)
 {
-    const unsigned w = waves_per_wg < 1u ? 1u : (waves_per_wg > PLL_MAX_WAVES ? PLL_MAX_WAVES : waves_per_wg);
-    const dim3 block(PLL_THREADS * w), grid((njobs + block.x - 1) / block.x + wg_skip);
-#define FX_PLL_CASE(M) case M: hipLaunchKernelGGL(fx_paypll_kernel<M>, grid, block, 0, st, jobs, job_idx, njobs, wg_skip, sym_raw, framesyms, hard, res, T); break;
-    switch (ms) {
-        FX_PLL_CASE(FX_MODEM_PSK2) FX_PLL_CASE(FX_MODEM_PSK4) FX_PLL_CASE(FX_MODEM_PSK8) FX_PLL_CASE(FX_MODEM_PSK16)
-        FX_PLL_CASE(FX_MODEM_DPSK2) FX_PLL_CASE(FX_MODEM_DPSK4) FX_PLL_CASE(FX_MODEM_DPSK8) FX_PLL_CASE(FX_MODEM_ASK4)
-        FX_PLL_CASE(FX_MODEM_QAM16) FX_PLL_CASE(FX_MODEM_QAM32) FX_PLL_CASE(FX_MODEM_QAM64) FX_PLL_CASE(FX_MODEM_QPSK)
-    default: return hipErrorInvalidValue;
-    }
+    const uint32_t nw = hdr->pll_base[FX_PLL_CLASSES] >> 6;
+    const uint32_t wpg = blockDim.x >> 6, w0 = blockIdx.x * wpg + (threadIdx.x >> 6);
+    if (blockIdx.x * wpg >= nw) return;
+    // a frame's PLL is one long dependent chain: when it shares a SIMD with walker / decoder waves of other
+    // blocks in flight, let it win the issue arbitration
+    __builtin_amdgcn_s_setprio(3);
+    __shared__ float2 sc[1024];
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) sc[i] = T->sc[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (uint32_t w = w0; w < nw; w += gridDim.x * wpg) {
+        uint32_t cls = 0;
+        while (cls + 1 < FX_PLL_CLASSES && (w << 6) >= hdr->pll_base[cls + 1]) cls++;
+        cls = __builtin_amdgcn_readfirstlane(cls);
+        const uint32_t f = pll_list[(w << 6) + lane];
+#define FX_PLL_CASE(C, M) case C: pll_frame<M>(f, jobs, sc, sym_raw, framesyms, hard, recs); break;
+        switch (cls) {
+            FX_PLL_CASE(0, FX_MODEM_PSK2) FX_PLL_CASE(1, FX_MODEM_PSK4) FX_PLL_CASE(2, FX_MODEM_PSK8) FX_PLL_CASE(3, FX_MODEM_PSK16)
+            FX_PLL_CASE(4, FX_MODEM_DPSK2) FX_PLL_CASE(5, FX_MODEM_DPSK4) FX_PLL_CASE(6, FX_MODEM_DPSK8) FX_PLL_CASE(7, FX_MODEM_ASK4)
+            FX_PLL_CASE(8, FX_MODEM_QAM16) FX_PLL_CASE(9, FX_MODEM_QAM32) FX_PLL_CASE(10, FX_MODEM_QAM64)
+            default: pll_frame<FX_MODEM_QPSK>(f, jobs, sc, sym_raw, framesyms, hard, recs); break;
+        }
 #undef FX_PLL_CASE
+    }
+}
+
+// host-side launcher
+extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
+                                       const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs, const FxTables *T)
+{
+    if (grid_waves == 0) return hipSuccess;
+    const unsigned w = waves_per_wg < 1u ? 1u : (waves_per_wg > PLL_MAX_WAVES ? PLL_MAX_WAVES : waves_per_wg);
+    hipLaunchKernelGGL(fx_paypll_kernel, dim3((grid_waves + w - 1) / w), dim3(PLL_THREADS * w), 0, st, jobs, pll_list, hdr, sym_raw, framesyms, hard, recs, T);
     return hipGetLastError();
 }
 
@@ -901,7 +1409,7 @@ extern "C" hipError_t fx_launch_paypll(unsigned ms, unsigned njobs, unsigned wg_
 
 __device__ __forceinline__ unsigned getbit(const uint8_t *b, uint32_t i) { return (b[i >> 3] >> (7 - (i & 7))) & 1u; }
 
-// gather-permute `nbytes` bytes bit by bit: dst bit i = src bit perm[i]
+// gather-permute `nbytes` bytes bit by bit: dst bit i = src bit perm[i] (frame generator: tables built by the host)
 __device__ __forceinline__ void permute_bits(const uint8_t *src, uint8_t *dst, const uint32_t *perm, uint32_t nbytes, int lane)
 {
     for (uint32_t j = lane; j < nbytes; j += DEC_THREADS) {
@@ -909,6 +1417,41 @@ __device__ __forceinline__ void permute_bits(const uint8_t *src, uint8_t *dst, c
 #pragma unroll
         for (int b = 0; b < 8; b++) v = (v << 1) | getbit(src, perm[8 * j + b]);
         dst[j] = (uint8_t)v;
+    }
+}
+
+// The packetizer's block interleaver, undone in place by one wave.  The interleaver is four passes of byte-pair swaps
+// under the bit masks ff / 0f / 55 / 33; a pass pairs even byte 2i with odd byte 2j+1, where j runs through
+// m Np + nn (m = 0..M-1 fastest, nn starting at n/3 and wrapping mod Np) skipping values >= n/2.  Within a pass no byte is
+// touched twice, so the lanes take 64 candidates at a time and rank the valid ones with a ballot; de-interleaving applies
+// the passes in reverse order.  No table, hence nothing for the host to prepare when a new packet length shows up.
+__device__ __forceinline__ void deinterleave_wave(uint8_t *x, uint32_t n, int lane)
+{
+    if (n < 2) return;
+    const uint32_t M = 1u + (uint32_t)floorf(sqrtf((float)n));
+    uint32_t N = n / M; while (n >= M * N) N++;
+    const uint32_t n2 = n / 2, nn0 = n / 3, step_q = 64u / M, step_m = 64u % M;
+    for (int p = 3; p >= 0; p--) {
+        const uint32_t Np = N + (p == 0 ? 0u : (p == 1 ? 2u : (p == 2 ? 4u : 8u)));
+        const uint32_t mk = p == 0 ? 0xffu : (p == 1 ? 0x0fu : (p == 2 ? 0x55u : 0x33u));
+        uint32_t m = (uint32_t)lane % M, q = (uint32_t)lane / M, i_base = 0;
+        const uint32_t max_iter = (M * (Np + 1u)) / 64u + 2u;                     // every (m, nn) pair at most once: cannot be reached
+        for (uint32_t it = 0; i_base < n2 && it < max_iter; it++) {
+            const uint32_t nn = q == 0 ? nn0 : (nn0 + q) % Np;
+            const uint32_t j = m * Np + nn;
+            const bool valid = j < n2;
+            const unsigned long long mask = __ballot(valid);
+            const uint32_t i = i_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (valid && i < n2) {
+                const uint32_t a = 2u * i, b = 2u * j + 1u;
+                const uint32_t va = x[a], vb = x[b];
+                x[a] = (uint8_t)((va & ~mk) | (vb & mk)); x[b] = (uint8_t)((va & mk) | (vb & ~mk));
+            }
+            i_base += (uint32_t)__popcll(mask);
+            m += step_m; q += step_q;
+            if (m >= M) { m -= M; q++; }
+        }
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1313,7 +1856,7 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 }
 
 #ifdef FX_STAMPS
-#define FX_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0) res[jf].stamp[i] = (uint32_t)(t_ - t_prev); t_prev = t_; } while (0)
+#define FX_STAMP(i) do { unsigned long long t_ = __builtin_readcyclecounter(); if (lane == 0 && res) res[jf].stamp[i] = (uint32_t)(t_ - t_prev); t_prev = t_; } while (0)
 #define FX_STAMP_INIT unsigned long long t_prev = __builtin_readcyclecounter()
 #else
 #define FX_STAMP(i) do { } while (0)
@@ -1329,12 +1872,17 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 #define DEC_MAX_WAVES 8
 template <bool WITH_RS>
 __global__ __launch_bounds__(WITH_RS ? DEC_THREADS : DEC_THREADS * DEC_MAX_WAVES)
-void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t njobs, const uint8_t *hard, const uint32_t *perm_arena, uint8_t *bufA,
-                      uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxPayResult *res, const FxTables *T)
+void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA,
+                      uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
 {
     __builtin_amdgcn_s_setprio(2);
+    // the list's length is known on the device only: the grid covers the list's capacity and surplus waves leave at once
+    // (a grid-stride loop around this body doubles its register footprint)
+    const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : hdr->n_dec_plain;
     const uint32_t ji = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (ji >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    {
     const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
     // one wave per frame: pin the loop bounds into SGPRs so that every loop below is scalar-controlled
@@ -1342,7 +1890,6 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
     job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
     job.fec0 = __builtin_amdgcn_readfirstlane(job.fec0); job.fec1 = __builtin_amdgcn_readfirstlane(job.fec1);
     job.bps = __builtin_amdgcn_readfirstlane(job.bps); job.check = __builtin_amdgcn_readfirstlane(job.check);
-    const int lane = threadIdx.x & 63;
     uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
     const uint8_t *hs = hard + job.sym_off;
     const unsigned bps = job.bps;
@@ -1359,31 +1906,34 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
     }
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(0);
-    // 2. outer plan (fec1): de-interleave l1, decode -> l0 bytes
-    permute_bits(A, B, perm_arena + job.perm1_off, job.l1, lane);
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // 2. outer plan (fec1): de-interleave l1 bytes in place, decode -> l0 bytes
+    deinterleave_wave(A, job.l1, lane);
     FX_STAMP(1);
     uint32_t status = 0;
     const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
-    if (pc1 == 1) viterbi27<false>(1, job.l0, B, A, dw_arena + job.dw_off, B, lane, nullptr);
-    else if (pc1) viterbi27<true>(pc1, job.l0, B, A, dw_arena + job.dw_off, B, lane, nullptr);
-    else block_fec_decode<WITH_RS>(job.fec1, job.l0, B, A, T, lane);
+    if (pc1 == 1) viterbi27<false>(1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
+    else if (pc1) viterbi27<true>(pc1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
+    else block_fec_decode<WITH_RS>(job.fec1, job.l0, A, B, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(2);
-    // 3. inner plan (fec0): de-interleave l0, decode -> k bytes
-    permute_bits(A, B, perm_arena + job.perm0_off, job.l0, lane);
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    // 3. inner plan (fec0): de-interleave l0 bytes in place, decode -> k bytes
+    deinterleave_wave(B, job.l0, lane);
     FX_STAMP(3);
-    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[jf].stamp[6]);
-    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, &res[jf].stamp[6]);
+    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
+    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
     else block_fec_decode<WITH_RS>(job.fec0, job.k, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(4);
-    // 4. de-whiten, CRC, copy out
+    // 4. de-whiten, CRC, copy out (the payload goes straight into the host's result arena)
     const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
     for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; j < job.pay_len; j += DEC_THREADS) out[(size_t)job.out_off + j] = A[j];
+    for (uint32_t j = lane; 4 * j < job.pay_len; j += DEC_THREADS) {                // out_off is a multiple of 16
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if (4 * j + b < job.pay_len) w |= (uint32_t)A[4 * j + b] << (8 * b);
+        reinterpret_cast<uint32_t *>(out + job.out_off)[j] = w;
+    }
     {
         const uint32_t cl = job.k - job.pay_len;
         uint32_t rx = 0, key = 0;
@@ -1402,21 +1952,23 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, uint32_t nj
         default: key = 0; break;
         }
         if (lane == 0) {
-            res[jf].payload_valid = (key == rx) ? 1u : 0u;
-            res[jf].status = status;
+            recs[jf].payload_valid = (key == rx) ? 1u : 0u;
+            recs[jf].status = status;
         }
     }
     FX_STAMP(5);
+    }
 }
 
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned njobs, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard,
-                                       const uint32_t *perm_arena, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
-                                       FxPayResult *res, const FxTables *T)
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+                                       const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
+                                       FxOutRec *recs, FxPayResult *res, const FxTables *T)
 {
+    if (grid_waves == 0) return hipSuccess;
     const unsigned w = with_rs ? 1u : (waves_per_wg < 1u ? 1u : (waves_per_wg > DEC_MAX_WAVES ? DEC_MAX_WAVES : waves_per_wg));
-    const dim3 grid((njobs + w - 1) / w), block(DEC_THREADS * w);
-    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, grid, block, 0, st, jobs, job_idx, njobs, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
-    else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, njobs, hard, perm_arena, bufA, bufB, dw_arena, out, res, T);
+    const dim3 grid((grid_waves + w - 1) / w), block(DEC_THREADS * w);
+    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, grid, block, 0, st, jobs, job_idx, hdr, hard, bufA, bufB, dw_arena, out, recs, res, T);
+    else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, hdr, hard, bufA, bufB, dw_arena, out, recs, res, T);
     return hipGetLastError();
 }
 

@@ -167,18 +167,16 @@ void      fxrx_reset(fxrx_ctx *c);
 int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
 int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out);
 
-/* Pipelined form of fxrx_process (= submit + collect).  fxrx_submit launches the walkers of the new block and runs
- * one host phase each of the (at most two) blocks submitted before it: the older one gets its payload stages queued,
- * the younger one is stitched and its seek verification launched.  fxrx_collect waits for the OLDEST submitted block
- * (running its remaining host phases first if nobody has) and exposes its results through fxrx_result /
- * fxrx_last_timing.  With depth d (fxrx_set_depth, 1..16, default 1) up to d blocks may be in flight, each on its own
- * payload stream.  After fxrx_reset a block is independent of the ones before it and is walked at once; a block that
- * continues the streams of the previous one is walked speculatively (blocks of >= 2^18 samples per stream, <= 8
- * streams: all but the first walker of each stream start at once, the first joins when the previous block's tail is
- * known) or, when small, only after the previous block has run all its host phases.  Blocks of one stream must be
- * submitted in order; device input buffers must stay valid until their block has been collected; results stay valid
- * until the next fxrx_collect / fxrx_process on the context.  Returns 0 (submit) / result count (collect) or
- * FXRX_ERR_*. */
+/* Pipelined form of fxrx_process (= submit + collect).  fxrx_submit enqueues the block's whole kernel chain on the block's
+ * own HIP stream -- walkers, seek verification, chain (stitch / repair / resume state), plan, payload MF, PLL, packet decode,
+ * results into pinned host memory -- and returns without waiting for any of it; what a stream carries from block to block
+ * (resume state, unconsumed tail) stays on the device, so a block that continues the streams of the previous one simply
+ * orders its first walkers behind that block's chain kernel.  fxrx_collect waits for the OLDEST submitted block and exposes
+ * its results through fxrx_result / fxrx_last_timing.  With depth d (fxrx_set_depth, 1..16, default 1) up to d blocks may
+ * be in flight.  After fxrx_reset the next block starts from a freshly reset synchroniser.  Blocks of one stream must be
+ * submitted in order; input buffers, host or device, must stay valid until their block has been collected; results stay
+ * valid until the next fxrx_collect / fxrx_process on the context (a submit in between does not touch them).  Returns 0
+ * (submit) / result count (collect) or FXRX_ERR_*. */
 int fxrx_set_depth(fxrx_ctx *c, unsigned int depth);
 int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
 int fxrx_collect(fxrx_ctx *c);
@@ -190,18 +188,20 @@ int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]);   /* slowest wal
 const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n_symbols);
 
 typedef struct {
-    double   walk_ms, paymf_ms, paypll_ms, paydec_ms, total_ms;   /* HIP-event times of the last call */
+    double   walk_ms, paymf_ms, paypll_ms, paydec_ms, total_ms;   /* HIP-event times of the block's kernels, on the stream they ran on */
     uint64_t hops, walk_jobs, repairs, frames, payload_symbols, samples, hops_cheap;
-    double   host_submit_ms, host_walkwait_ms;   /* wall time spent inside fxrx_submit / of that, waiting for the walker + seek verification */
+    double   host_submit_ms, host_walkwait_ms;   /* wall time inside fxrx_submit (descriptor build + enqueue) / always 0: the host no longer waits for the walkers */
     double   seekverify_ms;                      /* fx_seekverify_kernel (full detector over the hops the walkers skipped) */
-    uint64_t verify_hops, verify_failures;
+    uint64_t verify_hops, verify_failures;       /* hops re-checked / runs on which the exact detector fired (those spans are walked again, exactly) */
     double   host_collectwait_ms;                /* wall time fxrx_collect waited for the block's results */
-    uint64_t walk_mode;                          /* 0 walked with known state, 1 speculatively across the block boundary, 2 re-staged */       /* hops re-checked / streams walked again because a skipped hop fired */
+    uint64_t walk_mode;                          /* 0: all streams started freshly reset, 1: some continued the previous block (true walkers ordered behind its chain kernel) */
+    double   chain_ms;                           /* fx_chain_kernel + fx_plan_kernel */
+    uint64_t replays;                            /* carry-buffer overflows handled so far (blocks behind the overflowing one were enqueued again) */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
-/* the first of the context's two walk streams (hipStream_t as void*): input staging, walkers and seek verification of the
- * even slots run on it; payload kernels run on per-slot payload streams.  To order external work against a block, use
- * fxrx_collect (it returns when the block's results are on the host). */
+/* the HIP stream (hipStream_t as void*) of the first slot of the ring of blocks in flight; every block runs its whole kernel
+ * chain on its slot's stream.  To order external work against a block, use fxrx_collect (it returns when the block's
+ * results are on the host). */
 void *fxrx_stream(const fxrx_ctx *c);
 
 /* batched frame generator: one frame -> samples (host) */

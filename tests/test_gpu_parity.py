@@ -437,13 +437,15 @@ def test_continuing_stream_is_walked_speculatively_across_blocks(fx, oracle, on_
 
 
 @pytest.mark.gpu
-def test_speculative_blocks_multi_stream_and_tail_longer_than_headroom(fx, oracle):
-    """Cross-block speculation with several streams of different block sizes, and with frames long enough (about 260 k
-    samples) that the tail carried over a cut exceeds the staging headroom: that block is re-staged and walked serially.
-    Everything must still equal the single pass."""
+@pytest.mark.parametrize("carry", [0, 65536, 4096])
+def test_continuing_multi_stream_blocks_and_tail_longer_than_the_carry_buffer(fx, oracle, monkeypatch, carry):
+    """Several streams of different block sizes fed as continuing blocks, several in flight, with frames long enough (about
+    260 k samples) that the tail carried over a cut exceeds the carry buffer (FXRX_CARRY_SAMPLES shrinks it): the state the
+    overflowing block leaves is invalid, the blocks behind it do nothing, and fxrx_collect grows the buffers and enqueues them
+    again.  Everything must still equal the single pass."""
     key = lambda g: (g["stream"], g["start"], g["payload"], g["payload_valid"], g["evm_sum"], g["rxy"], g["header_valid"])
-    # stream 0: short frames first (small tails -> small headroom), then PSK2 r1/2 frames of about 260 k samples: the cut at
-    # 700 k falls 150 k samples into the first of them
+    # stream 0: short frames first, then PSK2 r1/2 frames of about 260 k samples: the cut at 700 k falls 150 k samples into
+    # the first of them
     xs = [np.concatenate([fx.synth_stream(550_000, stream_id=84, payload_len=64)[0],
                           fx.synth_stream(850_000, stream_id=81, payload_len=8000, mod=1, fec0=11, gap=3000)[0]]),
           fx.synth_stream(1_150_000, stream_id=82, payload_len=500, mod=27, fec0=15)[0],
@@ -454,6 +456,7 @@ def test_speculative_blocks_multi_stream_and_tail_longer_than_headroom(fx, oracl
     assert len([r for r in ref if r[0] == 0 and len(r[2]) == 8000]) >= 2
     nblk = 4
     cuts = [[int(len(x) * k / nblk) + (137 * s if 0 < k < nblk else 0) for k in range(nblk + 1)] for s, x in enumerate(xs)]
+    if carry: monkeypatch.setenv("FXRX_CARRY_SAMPLES", str(carry))
     ctx = fx.RxContext(3)
     ctx.set_depth(3)
     got, inflight, parts_alive, modes = [], 0, [], []
@@ -466,7 +469,22 @@ def test_speculative_blocks_multi_stream_and_tail_longer_than_headroom(fx, oracl
     while inflight:
         got += ctx.results(ctx.collect_raw()); modes.append(ctx.timing()["walk_mode"]); inflight -= 1
     assert sorted(key(g) for g in got) == sorted(ref)
-    assert modes[0] == 0 and 2 in modes, "expected the first block serial and at least one re-staged block, got %r" % modes
+    assert modes == [0, 1, 1, 1]
+    if carry: assert ctx.timing()["replays"] >= 1, "the carry buffer never overflowed: the replay path was not exercised"
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_chain_kernel_general_path_equals_fast_path(fx, oracle, monkeypatch):
+    """fx_chain_kernel stitches through a parallel fast path when nothing needs repairing and through a sequential general
+    path otherwise; FXRX_CHAIN_SLOW=1 forces the general one.  Same frames either way, and both equal the oracle."""
+    x, inj = fx.synth_stream(700_000, stream_id=12, payload_len=200)
+    of = oracle_frames(oracle, x)
+    monkeypatch.setenv("FXRX_CHAIN_SLOW", "1")
+    for seg in (0, 4096, 30000):
+        ctx = fx.RxContext(1, want_framesyms=True, segment_len=seg)
+        compare_frames(of, ctx.process([x]))
+        ctx.close()
 
 
 @pytest.mark.gpu
