@@ -169,7 +169,8 @@ struct FxStreamDesc {
 };
 
 enum { FX_BLK_INVALID = 1 /* some stream started from an invalid state: nothing in this block counts */,
-       FX_BLK_CARRY_OVERFLOW = 2, FX_BLK_CHAIN_FULL = 4 /* chain table exhausted (sizing bug) */ };
+       FX_BLK_CARRY_OVERFLOW = 2, FX_BLK_CHAIN_FULL = 4 /* chain table exhausted (sizing bug) */,
+       FX_BLK_NEEDS_REPAIR = 8 /* fx_chainfast_kernel met something only the full-size chain kernel can do (a walk) */ };
 #define FX_PLL_CLASSES 12
 struct FxBlockHdr {                      // device memory, zeroed at submit; mirrored to the host by fx_plan_kernel
     uint32_t n_runs;                     // verification runs emitted (may exceed the capacity: the excess spans are marked bad)

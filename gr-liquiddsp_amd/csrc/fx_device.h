@@ -73,6 +73,15 @@ FX_DEV void sincos_u32(uint32_t th, const float2 *sc, float &c, float &s)
     s = fmaf(t.y, cd, t.x * sd);
 }
 
+// cos / sin of a small signed phase increment, 5th-order series (payload PLL: turns the carrier phasor between table look-ups)
+FX_DEV void sincos_small(uint32_t inc, float &c, float &s)
+{
+    float x  = (float)(int)inc * 1.4629180792671596e-9f;
+    float x2 = x * x;
+    c = fmaf(x2, fmaf(x2, 4.16666679e-2f, -0.5f), 1.0f);
+    s = fmaf(x * x2, fmaf(x2, 8.33333377e-3f, -0.16666667f), x);
+}
+
 // x * exp(-j theta)
 FX_DEV float2 derot(float2 x, uint32_t th, const float2 *sc)
 {
@@ -260,9 +269,7 @@ FX_DEV unsigned modem_demod(unsigned ms, unsigned bps, float2 r, unsigned &dpsk_
                          (2.0f * (float)iq - (float)((1u << mq) - 1u)) * al);
         break; }
     }
-    float pr = fmaf(r.x, xh.x, r.y * xh.y);
-    float pi = fmaf(r.y, xh.x, -(r.x * xh.y));
-    pe = atan2c(pi, pr);
+    pe = fmaf(r.y, xh.x, -(r.x * xh.y));          // imag(r conj(xhat))
     return sym;
 }
 

@@ -46,14 +46,16 @@ extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const 
 extern "C" hipError_t fx_launch_chain(unsigned mode, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
                                       FxWalkResult *results, FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap,
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T);
+extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
+                                          const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair);
 extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
                                      uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_host);
+                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host);
 extern "C" hipError_t fx_launch_paymf(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                       float2 *sym_raw, const FxTables *T);
 extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs, const FxTables *T);
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
                                        const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
                                        FxOutRec *recs, FxPayResult *res, const FxTables *T);
 
@@ -132,7 +134,8 @@ struct Slot {
     PinBuf<uint8_t> hp_desc; DevBuf<uint8_t> d_desc;
     size_t NJ = 0, n_early = 0, n_late = 0, o_list = 0, o_streams = 0;
     // device tables
-    DevBuf<FxWalkResult> d_wres; DevBuf<FxFrame> d_frames, d_chain; DevBuf<FxVerifyRun> d_runs; DevBuf<FxBlockHdr> d_hdr;
+    DevBuf<FxWalkResult> d_wres; DevBuf<FxFrame> d_frames, d_chain; DevBuf<FxVerifyRun> d_runs;
+    DevBuf<FxBlockHdr> d_hdr;                // [0] walk-phase counters (zero between blocks), [1] what the payload kernels read
     DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list;
     DevBuf<FxPayJob> d_pjobs; DevBuf<FxPayResult> d_pres;
     uint32_t run_cap = 0, chain_cap = 0, mf_cap = 0, frame_slots = 0;
@@ -154,18 +157,18 @@ struct fxrx_ctx_s {
     std::vector<StreamState> st;
     FxStreamState *d_state = nullptr; FxStreamState *h_state = nullptr;   // [kStateRing][n_streams], device / pinned mirror
     bool skip_seek = true;               // FXRX_SKIP_SEEK=0: walkers run the full detector on every hop (nothing to verify)
-    bool chain_slow = false;             // FXRX_CHAIN_SLOW=1: the chain kernel always takes its general (sequential) path
+    bool chain_slow = false;             // FXRX_CHAIN_SLOW=1: every block goes through the full-size chain kernel's general (sequential) path
     unsigned pll_waves = 1, dec_waves = 1;   // waves per workgroup of the PLL / decode grids (placement only)
     int n_cus = 256;
     uint64_t seq = 0;                    // blocks submitted so far
     hipEvent_t prev_chain = nullptr;     // chain kernel of the newest submitted block (borrowed from its slot)
     hipEvent_t carry_reader[3] = { nullptr, nullptr, nullptr };   // payload MF of the newest block that reads carry[i]
     uint32_t verify_per = 4;             // hops per verification run (adapted to the traffic)
-    uint64_t frames_hint = 0;            // frames of the last collected block (sizes the PLL / decode grids)
+    uint64_t frames_hint = 0, rs_hint = 0;   // frames / Reed-Solomon frames of the last collected block (size the PLL / decode grids)
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
     Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
-    uint64_t replays = 0;
+    uint64_t replays = 0, repairs_host = 0;
 };
 
 namespace {
@@ -209,9 +212,9 @@ int upload_tables(fxrx_ctx_s *c)
     return 0;
 }
 
-// frame-table slots per walk job: one per 2048 samples of segment (+8).  A segment with more detections than slots
-// (650-sample frames back to back) is continued by the chain kernel (FX_EXIT_TABLE_FULL).
-inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 2048 + 8, 512); }
+// frame-table slots per walk job: the densest legal traffic is a header-only frame (618 samples) after the other.  (Should a
+// table fill up all the same -- FX_EXIT_TABLE_FULL -- the full-size chain kernel continues the segment.)
+inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 600 + 8, 4000); }
 
 int alloc_carry(StreamState &S, int64_t cap)
 {
@@ -245,8 +248,9 @@ static int make_slot(fxrx_ctx_s *c)
     HIP_OK(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
     for (auto &e : s->ev) HIP_OK(hipEventCreate(&e));
     s->index = (unsigned)c->slots.size();
-    if (s->h_hdr.reserve(1) || s->d_hdr.reserve(1)) return FXRX_ERR_HIP;
+    if (s->h_hdr.reserve(1) || s->d_hdr.reserve(2)) return FXRX_ERR_HIP;
     std::memset(s->h_hdr.p, 0, sizeof(FxBlockHdr));
+    HIP_OK(hipMemset(s->d_hdr.p, 0, 2 * sizeof(FxBlockHdr)));     // (fx_plan_kernel zeroes the counters again after every block)
     c->slots.push_back(std::move(s));
     return 0;
 }
@@ -332,6 +336,8 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
     return c->last->n_syms ? c->last->d_framesyms.p : nullptr;
 }
 
+static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full);
+
 // ---- enqueue the whole kernel chain of the block in `sl` (descriptors are rebuilt: a replay calls this again) ----
 static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
 {
@@ -381,7 +387,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
             j.mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
             j.handoff = j.stop < ns ? 1u : 0u;
             j.prelock = first ? 0u : 1u;
-            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && cont ? 65536u : 0u));
+            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && cont ? (uint64_t)sn.carry_bound : 0u));
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
             j.no_skip = (detect || !c->skip_seek) ? 1u : 0u;
@@ -432,49 +438,76 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     std::memcpy(sl.hp_desc.p + o_streams, sds.data(), NS * sizeof(FxStreamDesc));
     const FxWalkJob *d_jobs = reinterpret_cast<const FxWalkJob *>(sl.d_desc.p);
     const uint32_t *d_list = reinterpret_cast<const uint32_t *>(sl.d_desc.p + o_list);
-    const FxStreamDesc *d_streams = reinterpret_cast<const FxStreamDesc *>(sl.d_desc.p + o_streams);
     const unsigned mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
 
-    // ---- 3. the chain ----
+    // ---- 3. the chain, front part: walkers and seek verification ----
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
-    HIP_OK(hipMemsetAsync(sl.d_hdr.p, 0, sizeof(FxBlockHdr), st));
     HIP_OK(hipEventRecord(sl.ev[0], st));
     HIP_OK(fx_launch_walk(mode, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
-    // the true walkers of continuing streams read the state the previous block's chain kernel leaves; chain kernels run in
-    // block order in any case (they write the carry buffers in rotation)
-    if (c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
-    HIP_OK(fx_launch_walk(mode, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
+    // the true walkers of continuing streams read the state the previous block's chain kernel leaves
+    if (!late.empty()) {
+        if (c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
+        HIP_OK(fx_launch_walk(mode, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
+    }
     HIP_OK(hipEventRecord(sl.ev[1], st));
     if (!detect && c->skip_seek)
         HIP_OK(fx_launch_seekverify(4u * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables));
     HIP_OK(hipEventRecord(sl.ev[2], st));
-    // this block's chain kernel writes carry[(b + 1) % 3]: the payload MF of block b - 2 may still be reading it
+    // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
+    // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
+    if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
     if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(st, c->carry_reader[(b + 1) % 3], 0));
-    HIP_OK(fx_launch_chain(mode, NS, st, d_streams, d_jobs, (uint32_t)NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
-                           sl.d_hdr.p, c->chain_slow ? 1u : 0u, c->d_tables));
+    return enqueue_back(c, sl, false);
+}
+
+// ---- back part of the chain: chain kernel, plan, payload stage.  `full`: the full-size chain kernel, which can walk
+// (fxrx_collect runs it for a block whose lean chain kernel reported FX_BLK_NEEDS_REPAIR) ----
+static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
+{
+    const unsigned NS = c->cfg.n_streams;
+    const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
+    const unsigned mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
+    const uint64_t b = sl.seq;
+    hipStream_t st = sl.st;
+    const FxWalkJob *d_jobs = reinterpret_cast<const FxWalkJob *>(sl.d_desc.p);
+    const FxStreamDesc *d_streams = reinterpret_cast<const FxStreamDesc *>(sl.d_desc.p + sl.o_streams);
+    const uint32_t chain_slots = sl.chain_cap, list_cap = chain_slots + 64 * FX_PLL_CLASSES;
+    FxBlockHdr *hdr = sl.d_hdr.p, *hdr_pay = sl.d_hdr.p + 1;
+    if (full)
+        HIP_OK(fx_launch_chain(mode, NS, st, d_streams, d_jobs, (uint32_t)sl.NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
+                               hdr, c->chain_slow ? 1u : 0u, c->d_tables));
+    else
+        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u));
     HIP_OK(hipEventRecord(sl.ev[3], st));
     c->prev_chain = sl.ev[3];
     HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
-                          sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap, sl.d_hdr.p, sl.h_hdr.p));
+                          sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap, hdr, hdr_pay, sl.h_hdr.p));
     HIP_OK(hipEventRecord(sl.ev[4], st));
     if (!detect) {
         // grids stride over lists whose lengths only the device knows; size them from what the last block held
         const uint64_t fh = c->frames_hint ? std::min<uint64_t>(chain_slots, c->frames_hint + c->frames_hint / 2 + 64) : chain_slots;
         const unsigned mf_grid = (unsigned)std::min<uint64_t>(sl.mf_cap, 8ull * (uint64_t)c->n_cus);
-        HIP_OK(fx_launch_paymf(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, sl.d_hdr.p, sl.d_symraw.p, c->d_tables));
+        HIP_OK(fx_launch_paymf(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_symraw.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[5], st));
         c->carry_reader[b % 3] = sl.ev[5];
-        HIP_OK(fx_launch_paypll((unsigned)(fh / 64 + FX_PLL_CLASSES), c->pll_waves, st, sl.d_pjobs.p, sl.d_pll_list.p, sl.d_hdr.p, sl.d_symraw.p, sl.d_framesyms.p,
+        HIP_OK(fx_launch_paypll((unsigned)(fh / 64 + FX_PLL_CLASSES), c->pll_waves, st, sl.d_pjobs.p, sl.d_pll_list.p, hdr_pay, sl.d_symraw.p, sl.d_framesyms.p,
                                 sl.d_hard.p, sl.h_recs.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[6], st));
         FxPayResult *pres = nullptr;
 #ifdef FX_STAMPS
         pres = sl.d_pres.p;
 #endif
-        // decode: one wave per frame, the grid covers the list capacity (surplus waves exit at once)
-        HIP_OK(fx_launch_paydec(0, chain_slots, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, sl.d_hdr.p, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p,
+        // decode: one wave per frame.  The lean instance has no loop (it would double its registers): its grid covers what
+        // the last block held plus a margin, and a second, usually empty launch covers the rest of the list's capacity in
+        // big workgroups (few of them).  The Reed-Solomon instance strides.
+        const unsigned dec_first = (unsigned)std::min<uint64_t>(chain_slots, fh);
+        HIP_OK(fx_launch_paydec(0, 0, dec_first, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p,
                                 sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
-        HIP_OK(fx_launch_paydec(1, chain_slots, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, sl.d_hdr.p, sl.d_hard.p, sl.d_bufA.p,
+        if (dec_first < chain_slots)
+            HIP_OK(fx_launch_paydec(0, dec_first, chain_slots - dec_first, 8u, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
+                                    sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+        const unsigned rs_grid = (unsigned)std::min<uint64_t>(chain_slots, std::max<uint64_t>(64, c->rs_hint + c->rs_hint / 2));
+        HIP_OK(fx_launch_paydec(1, 0, rs_grid, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
                                 sl.d_bufB.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[7], st));
         // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
@@ -526,36 +559,53 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     return 0;
 }
 
-// A tail did not fit its carry buffer: block `sl` produced it (its own results are good), every block behind it found no
-// state and did nothing.  Grow the buffers, put the tail where the next block expects it, repair the state record, and
-// enqueue the blocks behind it again, in order.
-static int replay_after(fxrx_ctx_s *c, Slot &sl)
+// Two things the device cannot finish by itself, both rare, both handled here when the block concerned is collected:
+//  * FX_BLK_NEEDS_REPAIR: the lean chain kernel met a stretch that has to be walked again (a hand-off target missing from
+//    the next list, a skipped hop on which the exact detector fires, a full frame table).  The full-size chain kernel does
+//    that; the block's back part (chain, plan, payload) is enqueued again with it.
+//  * FX_BLK_CARRY_OVERFLOW: a tail did not fit its carry buffer.  The block's own results are good; the buffers are grown
+//    and the tail is copied by hand.
+// Either way the state the block left was marked invalid, so every block behind it did nothing: they are enqueued again,
+// in order, once the state is there.
+static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
 {
     const unsigned NS = c->cfg.n_streams;
     const unsigned nslots = c->depth + 1;
-    for (auto &s : c->slots) if (s->busy) HIP_OK(hipStreamSynchronize(s->st));
-    const uint64_t b = sl.seq;
-    FxStreamState *hs = c->h_state + (b % kStateRing) * NS, *ds = c->d_state + (b % kStateRing) * NS;
-    for (unsigned s = 0; s < NS; s++) {
-        if (!hs[s].overflow) continue;
-        StreamState &S = c->st[s];
-        const int64_t keep = hs[s].carry_len, old_cap = S.carry_cap;
-        float2 *old[3] = { S.carry[0], S.carry[1], S.carry[2] };
-        S.carry[0] = S.carry[1] = S.carry[2] = nullptr;
-        int64_t cap = std::max<int64_t>(2 * old_cap, 2 * keep); cap = (cap + 4095) & ~(int64_t)4095;
-        if (alloc_carry(S, cap)) return FXRX_ERR_HIP;
-        // tail = logical samples [n - keep, n) of block b: a piece of its own carried tail (old buffer b % 3), then its new samples
-        const int64_t nb = (int64_t)sl.n[s], from = nb - keep;
-        float2 *dst = S.carry[(b + 1) % 3] + cap - keep;
-        if (from < 0) HIP_OK(hipMemcpy(dst, old[b % 3] + old_cap + from, (size_t)(-from) * sizeof(float2), hipMemcpyDeviceToDevice));
-        const int64_t n_new = std::min<int64_t>(keep, nb);
-        if (n_new > 0) HIP_OK(hipMemcpy(dst + (keep - n_new), sl.x[s] + (nb - n_new), (size_t)n_new * sizeof(float2), hipMemcpyDeviceToDevice));
-        for (auto p : old) if (p) (void)hipFree(p);
-        hs[s].overflow = 0; hs[s].invalid = 0;
-        HIP_OK(hipMemcpy(ds + s, hs + s, sizeof(FxStreamState), hipMemcpyHostToDevice));
+    for (int round = 0; round < 4; round++) {
+        for (auto &s : c->slots) if (s->busy) HIP_OK(hipStreamSynchronize(s->st));
+        const uint32_t flags = sl.h_hdr.p->flags;
+        if (flags & FX_BLK_NEEDS_REPAIR) {
+            c->repairs_host++;
+            if (enqueue_back(c, sl, true)) return FXRX_ERR_HIP;
+            continue;                                   // (its tail may in turn overflow the carry buffer)
+        }
+        if (!(flags & FX_BLK_CARRY_OVERFLOW)) break;
+        const uint64_t b = sl.seq;
+        FxStreamState *hs = c->h_state + (b % kStateRing) * NS, *ds = c->d_state + (b % kStateRing) * NS;
+        for (unsigned s = 0; s < NS; s++) {
+            if (!hs[s].overflow) continue;
+            StreamState &S = c->st[s];
+            const int64_t keep = hs[s].carry_len, old_cap = S.carry_cap;
+            float2 *old[3] = { S.carry[0], S.carry[1], S.carry[2] };
+            S.carry[0] = S.carry[1] = S.carry[2] = nullptr;
+            int64_t cap = std::max<int64_t>(2 * old_cap, 2 * keep); cap = (cap + 4095) & ~(int64_t)4095;
+            if (alloc_carry(S, cap)) return FXRX_ERR_HIP;
+            // tail = logical samples [n - keep, n) of block b: a piece of its own carried tail (old buffer b % 3), then its new samples
+            const int64_t nb = (int64_t)sl.n[s], from = nb - keep;
+            float2 *dst = S.carry[(b + 1) % 3] + cap - keep;
+            if (from < 0) HIP_OK(hipMemcpy(dst, old[b % 3] + old_cap + from, (size_t)(-from) * sizeof(float2), hipMemcpyDeviceToDevice));
+            const int64_t n_new = std::min<int64_t>(keep, nb);
+            if (n_new > 0) HIP_OK(hipMemcpy(dst + (keep - n_new), sl.x[s] + (nb - n_new), (size_t)n_new * sizeof(float2), hipMemcpyDeviceToDevice));
+            for (auto p : old) if (p) (void)hipFree(p);
+            hs[s].overflow = 0; hs[s].invalid = 0;
+            HIP_OK(hipMemcpy(ds + s, hs + s, sizeof(FxStreamState), hipMemcpyHostToDevice));
+        }
+        sl.h_hdr.p->flags &= ~(uint32_t)FX_BLK_CARRY_OVERFLOW;
+        c->replays++;
+        break;
     }
-    c->replays++;
-    // the blocks behind it, oldest first (descriptors are rebuilt: the carry buffers moved)
+    if (sl.h_hdr.p->flags & (FX_BLK_NEEDS_REPAIR | FX_BLK_CARRY_OVERFLOW)) { set_err("fxrx_collect: block could not be repaired"); return FXRX_ERR_STATE; }
+    // the blocks behind it, oldest first (descriptors are rebuilt: carry buffers may have moved)
     c->prev_chain = sl.ev[3];
     for (unsigned k = 1; k < c->inflight; k++) {
         Slot &nx = *c->slots[(c->tail + k) % nslots];
@@ -582,7 +632,7 @@ int fxrx_collect(fxrx_ctx *c)
         if (flags & FX_BLK_CHAIN_FULL) { set_err("fxrx_collect: chain table overflow (internal sizing error)"); return FXRX_ERR_STATE; }
         // (an invalid block sits behind an overflowing one, whose collect replays it before it is collected itself)
         if (flags & FX_BLK_INVALID) { set_err("fxrx_collect: block has no valid start state"); return FXRX_ERR_STATE; }
-        if (flags & FX_BLK_CARRY_OVERFLOW) { if (replay_after(c, sl)) return FXRX_ERR_HIP; }
+        if (flags & (FX_BLK_CARRY_OVERFLOW | FX_BLK_NEEDS_REPAIR)) { int r = repair_and_replay(c, sl); if (r) return r; }
     }
     sl.timing.host_collectwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
     const FxBlockHdr &h = *sl.h_hdr.p;
@@ -614,7 +664,7 @@ int fxrx_collect(fxrx_ctx *c)
         if (!S.fresh_start && S.total >= end_total)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
-    c->frames_hint = h.n_frames;
+    c->frames_hint = h.n_frames; c->rs_hint = h.n_dec_rs;
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
     float ms = 0;
@@ -629,7 +679,7 @@ int fxrx_collect(fxrx_ctx *c)
     t.total_ms = t.walk_ms + t.seekverify_ms + t.chain_ms + t.paymf_ms + t.paypll_ms + t.paydec_ms;
     t.hops = h.hops; t.hops_cheap = h.hops_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs; t.frames = h.n_frames;
     t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops; t.verify_failures = h.verify_failures;
-    t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays;
+    t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays + c->repairs_host;
     sl.busy = false; c->last = &sl;
     c->tail = (c->tail + 1) % nslots; c->inflight--;
     return (int)sl.out.size();
@@ -644,8 +694,25 @@ int fxrx_process(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, 
     return fxrx_collect(c);
 }
 
-int fxrx_debug_walk_stamps(const fxrx_ctx *c, uint64_t out[4]) { if (!c) return FXRX_ERR_ARG; for (int i = 0; i < 4; i++) out[i] = 0; return 0; }
-int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]) { if (!c) return FXRX_ERR_ARG; for (int i = 0; i < 8; i++) out[i] = 0; return 0; }
+// diagnostic builds (-DFX_STAMPS): walker phase clocks of the last collected block, summed over its walk jobs / of the slowest job
+static int walk_stamps(const fxrx_ctx *c, uint64_t sum[4], uint64_t maxjob[8])
+{
+    for (int i = 0; i < 4; i++) sum[i] = 0;
+    for (int i = 0; i < 8; i++) maxjob[i] = 0;
+#ifdef FX_STAMPS
+    if (!c->last || !c->last->NJ) return 0;
+    std::vector<FxWalkResult> r(c->last->NJ);
+    if (hipMemcpy(r.data(), c->last->d_wres.p, r.size() * sizeof(FxWalkResult), hipMemcpyDeviceToHost) != hipSuccess) return FXRX_ERR_HIP;
+    for (const auto &w : r) {
+        uint64_t tot = 0;
+        for (int i = 0; i < 4; i++) { sum[i] += w.stamp[i]; tot += w.stamp[i]; }
+        if (tot > maxjob[7]) { for (int i = 0; i < 4; i++) maxjob[i] = w.stamp[i]; maxjob[4] = w.hops; maxjob[5] = w.hops_cheap; maxjob[6] = w.n_frames; maxjob[7] = tot; }
+    }
+#endif
+    return 0;
+}
+int fxrx_debug_walk_stamps(const fxrx_ctx *c, uint64_t out[4]) { if (!c) return FXRX_ERR_ARG; uint64_t mj[8]; return walk_stamps(c, out, mj); }
+int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]) { if (!c) return FXRX_ERR_ARG; uint64_t sm[4]; return walk_stamps(c, sm, out); }
 
 // diagnostic: decode-phase shader-clock deltas of frame i of the last collected block (zeros unless built with -DFX_STAMPS)
 int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8])

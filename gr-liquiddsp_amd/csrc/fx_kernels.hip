@@ -829,7 +829,14 @@ extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const 
 // Fast path (no repair needed anywhere, at most CHAIN_MAXJ segments): hand-off look-ups for all segments in parallel,
 // a pointer chase through LDS, parallel compaction.  Anything else takes the general sequential loop below it.
 #define CHAIN_MAXJ 2048
-#define CHAIN_NONE 1023u
+#define CHAIN_NONE 4095u
+
+struct ChainLds {
+    uint32_t lk[CHAIN_MAXJ], info[CHAIN_MAXJ], base[CHAIN_MAXJ];
+    float    rxy[CHAIN_MAXJ];
+    uint16_t m[CHAIN_MAXJ], pred[CHAIN_MAXJ], skip[CHAIN_MAXJ];
+    uint32_t sh[8];
+};
 
 __device__ __forceinline__ void wg_sync_global() { __threadfence(); __syncthreads(); __threadfence(); }
 
@@ -840,6 +847,166 @@ __device__ __forceinline__ void copy_frame(FxFrame *dst, const FxFrame *src)
     for (int i = 0; i < (int)(sizeof(FxFrame) / 8); i++) b[i] = a[i];
 }
 
+// Fast path of the chain (nothing to repair, at most CHAIN_MAXJ segments): returns false when the general path is needed.
+template <int NT>
+__device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const FxWalkJob *jobs, const FxWalkResult *results, const FxFrame *frames, FxFrame *out,
+                                                ChainLds &C, uint32_t &cnt, int64_t &fin_pos, int64_t &fin_floor, bool &fin_fresh)
+{
+    const int tid = threadIdx.x;
+    const uint32_t first = sd.first_job, nj = sd.n_jobs;
+    if (nj > CHAIN_MAXJ) return false;
+    // A. every segment: its own summary and the look-up of its hand-off target in the list it points at
+    for (uint32_t j = tid; j < nj; j += NT) {
+        const FxWalkResult &R = results[first + j];
+        const FxFrame *F = frames + jobs[first + j].frame_base;
+        uint32_t nf = R.n_frames; const uint32_t ex = R.exit_code;
+        if (ex == FX_EXIT_PAYLOAD && nf > 0) nf--;
+        uint32_t cntE = 0;
+        for (uint32_t i = 0; i < nf; i++) cntE += (F[i].flags & FX_FLAG_EXACT) ? 1u : 0u;
+        C.info[j] = nf | (cntE << 12) | (ex << 24) | ((R.has_handoff ? 1u : 0u) << 27) | (((R.tail_flags & FX_FLAG_SPAN_BAD) ? 1u : 0u) << 28) | ((nf >= CHAIN_NONE ? 1u : 0u) << 29);
+        C.rxy[j] = R.handoff_rxy;
+        uint32_t lk = CHAIN_NONE << 11, skipE = 0;
+        if (R.has_handoff && ex == FX_EXIT_STOP && j + 1 < nj) {
+            uint32_t nxt = j + 1;
+            while (nxt + 1 < nj && R.handoff_start >= jobs[first + nxt].stop + FX_HOP) nxt++;
+            const FxWalkResult &RN = results[first + nxt]; const FxFrame *FN = frames + jobs[first + nxt].frame_base;
+            uint32_t found = CHAIN_NONE, eb = 0;
+            uint32_t nfn = RN.n_frames, nfe = nfn; if (RN.exit_code == FX_EXIT_PAYLOAD && nfe > 0) nfe--;
+            // A frame is a function of (start, CFO bin) alone only if no sample it reads was masked by a zero-floor: splice
+            // only when both floors lie at or below the start; else the segment is walked from the true state.
+            for (uint32_t i = 0; R.handoff_clear && i < nfn && i < CHAIN_NONE; i++) {
+                const uint32_t fl = FN[i].flags;
+                if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; skipE = eb; break; }
+                if ((fl & FX_FLAG_EXACT) && i < nfe) eb++;
+            }
+            lk = nxt | (found << 11);
+        }
+        C.lk[j] = lk; C.skip[j] = (uint16_t)skipE; C.m[j] = 0xFFFFu;
+    }
+    __syncthreads();
+    // B. the chain itself: a pointer chase through LDS
+    if (tid == 0) {
+        uint32_t cur = 0, m = 0, base = 0, skipE = 0, pred = 0xFFFFu, problem = 0, endjob = 0, end_nothing = 0;
+        bool spliced = false;
+        for (;;) {
+            const uint32_t inf = C.info[cur], nf = inf & 4095u, cntE = (inf >> 12) & 4095u, ex = (inf >> 24) & 7u;
+            C.m[cur] = (uint16_t)(m | (spliced ? 0x8000u : 0u)); C.base[cur] = base; C.pred[cur] = (uint16_t)pred;
+            base += cntE - skipE;
+            const bool nothing = spliced && nf <= m;
+            if ((inf >> 29) & 1u) { problem = 1; break; }
+            if (!nothing && ((inf >> 28) & 1u)) { problem = 1; break; }            // a skipped hop of its tail seek fires
+            if (ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID) { problem = 1; break; }
+            if (cur + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u)) { endjob = cur; end_nothing = nothing ? 1u : 0u; break; }
+            const uint32_t lk = C.lk[cur], found = (lk >> 11) & 4095u;
+            if (found == CHAIN_NONE) { problem = 1; break; }                        // target not in the next list: repair
+            pred = cur; spliced = true; m = found; skipE = C.skip[cur]; cur = lk & 2047u;
+        }
+        C.sh[0] = problem; C.sh[1] = endjob; C.sh[2] = end_nothing; C.sh[3] = base;
+        if (base > sd.chain_cap) C.sh[0] = 1;
+    }
+    __syncthreads();
+    // C. compaction, one thread per segment on the chain
+    if (!C.sh[0]) {
+        for (uint32_t j = tid; j < nj; j += NT) {
+            const uint32_t cm = C.m[j];
+            if (cm == 0xFFFFu) continue;
+            const uint32_t m = cm & 0x7FFFu, nf = C.info[j] & 4095u; const bool spliced = (cm & 0x8000u) != 0;
+            const FxFrame *F = frames + jobs[first + j].frame_base;
+            uint32_t o = C.base[j];
+            for (uint32_t i = m; i < nf; i++) {
+                const uint32_t fl = F[i].flags;
+                if (!(fl & FX_FLAG_EXACT)) continue;
+                const bool own = !(spliced && i == m);
+                if (own && (fl & FX_FLAG_SPAN_BAD)) C.sh[0] = 1;
+                copy_frame(out + o, F + i);
+                if (!own) out[o].rxy = C.rxy[C.pred[j]];                            // coarse peak as the true chain saw it
+                o++;
+            }
+        }
+    }
+    __syncthreads();
+    const bool ok = !C.sh[0];
+    if (ok) {
+        const uint32_t ej = C.sh[1];
+        const FxWalkResult &R = C.sh[2] ? results[first + C.pred[ej]] : results[first + ej];
+        fin_pos = R.pos; fin_floor = R.floor; fin_fresh = R.fresh != 0; cnt = C.sh[3];
+    }
+    __syncthreads();
+    return ok;
+}
+
+// resume state, carried tail, frame count of a stream's chain
+template <int NT>
+__device__ __forceinline__ void chain_finish(const FxStreamDesc &sd, uint32_t s, const FxStreamState &st_in, uint32_t cnt, int64_t fin_pos, int64_t fin_floor,
+                                             bool fin_fresh, uint32_t *chain_count, FxBlockHdr *hdr)
+{
+    const int tid = threadIdx.x;
+    const XSrc xs = { sd.x, sd.xa_end, sd.n };
+    if (cnt > sd.chain_cap) { if (tid == 0) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CHAIN_FULL); cnt = sd.chain_cap; }
+    int64_t keep_from = fin_fresh ? fin_pos : fin_pos - FX_HOP;
+    keep_from = max(-st_in.carry_len, min(keep_from, sd.n));
+    const int64_t keep = sd.n - keep_from;
+    const bool overflow = keep > sd.carry_cap;
+    if (!overflow)
+        for (int64_t i = tid; i < keep; i += NT) sd.carry_out_end[i - keep] = xld(xs, keep_from + i);
+    if (tid == 0) {
+        FxStreamState so;
+        so.pos = fin_pos - sd.n; so.floor = max(fin_floor - sd.n, -keep); so.carry_len = keep; so.fresh = fin_fresh ? 1u : 0u;
+        so.invalid = overflow ? 1u : 0u; so.overflow = overflow ? 1u : 0u; so.pad_ = 0;
+        *sd.state_out = so; *sd.state_out_host = so;
+        chain_count[s] = cnt;
+        if (overflow) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CARRY_OVERFLOW);
+    }
+}
+
+__device__ __forceinline__ bool chain_state_in(const FxStreamDesc &sd, uint32_t s, FxStreamState &st_in, uint32_t *chain_count, FxBlockHdr *hdr)
+{
+    st_in.pos = 0; st_in.floor = 0; st_in.carry_len = 0; st_in.fresh = 1; st_in.invalid = 0; st_in.overflow = 0; st_in.pad_ = 0;
+    if (sd.state_in) st_in = *sd.state_in;
+    if (!st_in.invalid) return true;
+    if (threadIdx.x == 0) {                                     // nothing to build on: say so downstream, the host replays
+        FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
+        *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
+        atomicOr(&hdr->flags, (uint32_t)FX_BLK_INVALID);
+    }
+    return false;
+}
+
+// The kernel every block runs: the fast path only, small enough (256 threads, 45 KB of LDS, few registers) to find room on
+// a chip busy with the walkers and payload kernels of the other blocks in flight.  A stream that needs a repair is left
+// without a chain and without a state (FX_BLK_NEEDS_REPAIR): fxrx_collect then runs fx_chain_kernel -- the full-size one,
+// which can walk -- for the block and enqueues the blocks behind it again.
+#define CHAINFAST_THREADS 256
+extern "C" __global__ __launch_bounds__(CHAINFAST_THREADS)
+void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results, const FxFrame *frames, FxFrame *chain,
+                         uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair)
+{
+    __shared__ ChainLds C;
+    const uint32_t s = blockIdx.x;
+    const FxStreamDesc sd = streams[s];
+    FxStreamState st_in;
+    if (!chain_state_in(sd, s, st_in, chain_count, hdr)) return;
+    uint32_t cnt = 0; int64_t fin_pos = 0, fin_floor = 0; bool fin_fresh = true;
+    const bool ok = !force_repair && chain_fast_path<CHAINFAST_THREADS>(sd, jobs, results, frames, chain + sd.chain_base, C, cnt, fin_pos, fin_floor, fin_fresh);
+    if (!ok) {
+        if (threadIdx.x == 0) {
+            FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
+            *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
+            atomicOr(&hdr->flags, (uint32_t)FX_BLK_NEEDS_REPAIR);
+        }
+        return;
+    }
+    chain_finish<CHAINFAST_THREADS>(sd, s, st_in, cnt, fin_pos, fin_floor, fin_fresh, chain_count, hdr);
+}
+
+extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
+                                          const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair)
+{
+    hipLaunchKernelGGL(fx_chainfast_kernel, dim3(nstreams), dim3(CHAINFAST_THREADS), 0, st, streams, jobs, results, frames, chain, chain_count, hdr, force_repair);
+    return hipGetLastError();
+}
+
+// The full-size chain kernel: same fast path, and behind it the general, sequential one that can walk.
 template <int MODE, int WW>
 __global__ __launch_bounds__(64 * WW, 1)
 void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total, FxWalkResult *results, FxFrame *frames,
@@ -848,112 +1015,22 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
 {
     constexpr int NT = 64 * WW;
     __shared__ WalkLdsT<WW> L;
-    __shared__ uint32_t c_lk[CHAIN_MAXJ], c_info[CHAIN_MAXJ], c_base[CHAIN_MAXJ];
-    __shared__ float c_rxy[CHAIN_MAXJ];
-    __shared__ uint16_t c_m[CHAIN_MAXJ], c_pred[CHAIN_MAXJ];
-    __shared__ uint32_t c_sh[8];
+    __shared__ ChainLds C;
     const uint32_t s = blockIdx.x;
     const FxStreamDesc sd = streams[s];
     const int tid = threadIdx.x, lane = tid & 63;
-    const XSrc xs = { sd.x, sd.xa_end, sd.n };
     FxFrame *out = chain + sd.chain_base;
-    FxStreamState st_in; st_in.pos = 0; st_in.floor = 0; st_in.carry_len = 0; st_in.fresh = 1; st_in.invalid = 0; st_in.overflow = 0; st_in.pad_ = 0;
-    if (sd.state_in) st_in = *sd.state_in;
-    if (st_in.invalid) {                                     // nothing to build on: say so downstream, the host replays
-        if (tid == 0) {
-            FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
-            *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
-            atomicOr(&hdr->flags, (uint32_t)FX_BLK_INVALID);
-        }
-        return;
-    }
+    FxStreamState st_in;
+    if (!chain_state_in(sd, s, st_in, chain_count, hdr)) return;
     float2 twA[7], twB[7];
 #pragma unroll
     for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
     for (int i = tid; i < FX_NFFT; i += NT) L.S[i] = T->S[i];
 
-    const uint32_t first = sd.first_job, nj = sd.n_jobs, end = first + nj;
+    const uint32_t first = sd.first_job, end = first + sd.n_jobs;
     uint32_t cnt = 0;
     int64_t fin_pos = 0, fin_floor = 0; bool fin_fresh = true;
-    bool done = false;
-
-    // ------------------------------------------------------------------------------------------ fast path
-    if (!force_slow && nj <= CHAIN_MAXJ) {
-        // A. every segment: its own summary and the look-up of its hand-off target in the list it points at
-        for (uint32_t j = tid; j < nj; j += NT) {
-            const FxWalkResult &R = results[first + j];
-            const FxFrame *F = frames + jobs[first + j].frame_base;
-            uint32_t nf = R.n_frames; const uint32_t ex = R.exit_code;
-            if (ex == FX_EXIT_PAYLOAD && nf > 0) nf--;
-            uint32_t cntE = 0;
-            for (uint32_t i = 0; i < nf; i++) cntE += (F[i].flags & FX_FLAG_EXACT) ? 1u : 0u;
-            c_info[j] = nf | (cntE << 10) | (ex << 20) | ((R.has_handoff ? 1u : 0u) << 23) | (((R.tail_flags & FX_FLAG_SPAN_BAD) ? 1u : 0u) << 24);
-            c_rxy[j] = R.handoff_rxy;
-            uint32_t lk = CHAIN_NONE << 11;
-            if (R.has_handoff && ex == FX_EXIT_STOP && j + 1 < nj) {
-                uint32_t nxt = j + 1;
-                while (nxt + 1 < nj && R.handoff_start >= jobs[first + nxt].stop + FX_HOP) nxt++;
-                const FxWalkResult &RN = results[first + nxt]; const FxFrame *FN = frames + jobs[first + nxt].frame_base;
-                uint32_t found = CHAIN_NONE, skipE = 0, eb = 0;
-                uint32_t nfn = RN.n_frames, nfe = nfn; if (RN.exit_code == FX_EXIT_PAYLOAD && nfe > 0) nfe--;
-                for (uint32_t i = 0; R.handoff_clear && i < nfn && i < CHAIN_NONE; i++) {
-                    const uint32_t fl = FN[i].flags;
-                    if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; skipE = eb; break; }
-                    if ((fl & FX_FLAG_EXACT) && i < nfe) eb++;
-                }
-                lk = nxt | (found << 11) | (skipE << 21);
-            }
-            c_lk[j] = lk; c_m[j] = 0xFFFFu;
-        }
-        __syncthreads();
-        // B. the chain itself: a pointer chase through LDS
-        if (tid == 0) {
-            uint32_t cur = 0, m = 0, base = 0, skipE = 0, pred = 0xFFFFu, problem = 0, endjob = 0, end_nothing = 0;
-            bool spliced = false;
-            for (;;) {
-                const uint32_t inf = c_info[cur], nf = inf & 1023u, cntE = (inf >> 10) & 1023u, ex = (inf >> 20) & 7u;
-                c_m[cur] = (uint16_t)(m | (spliced ? 0x8000u : 0u)); c_base[cur] = base; c_pred[cur] = (uint16_t)pred;
-                base += cntE - skipE;
-                const bool nothing = spliced && nf <= m;
-                if (!nothing && ((inf >> 24) & 1u)) { problem = 1; break; }            // a skipped hop of its tail seek fires
-                if (ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID) { problem = 1; break; }
-                if (cur + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 23) & 1u)) { endjob = cur; end_nothing = nothing ? 1u : 0u; break; }
-                const uint32_t lk = c_lk[cur], found = (lk >> 11) & 1023u;
-                if (found == CHAIN_NONE) { problem = 1; break; }                        // target not in the next list: repair
-                pred = cur; spliced = true; m = found; skipE = lk >> 21; cur = lk & 2047u;
-            }
-            c_sh[0] = problem; c_sh[1] = endjob; c_sh[2] = end_nothing; c_sh[3] = base;
-            if (base > sd.chain_cap) c_sh[0] = 1;
-        }
-        __syncthreads();
-        // C. compaction, one thread per segment on the chain
-        if (!c_sh[0]) {
-            for (uint32_t j = tid; j < nj; j += NT) {
-                const uint32_t cm = c_m[j];
-                if (cm == 0xFFFFu) continue;
-                const uint32_t m = cm & 0x7FFFu, nf = c_info[j] & 1023u; const bool spliced = (cm & 0x8000u) != 0;
-                const FxFrame *F = frames + jobs[first + j].frame_base;
-                uint32_t o = c_base[j];
-                for (uint32_t i = m; i < nf; i++) {
-                    const uint32_t fl = F[i].flags;
-                    if (!(fl & FX_FLAG_EXACT)) continue;
-                    const bool own = !(spliced && i == m);
-                    if (own && (fl & FX_FLAG_SPAN_BAD)) c_sh[0] = 1;
-                    copy_frame(out + o, F + i);
-                    if (!own) out[o].rxy = c_rxy[c_pred[j]];                            // coarse peak as the true chain saw it
-                    o++;
-                }
-            }
-        }
-        __syncthreads();
-        if (!c_sh[0]) {
-            const uint32_t ej = c_sh[1];
-            const FxWalkResult &R = c_sh[2] ? results[first + c_pred[ej]] : results[first + ej];
-            fin_pos = R.pos; fin_floor = R.floor; fin_fresh = R.fresh != 0; cnt = c_sh[3];
-            done = true;
-        }
-        __syncthreads();
-    }
+    bool done = !force_slow && chain_fast_path<NT>(sd, jobs, results, frames, out, C, cnt, fin_pos, fin_floor, fin_fresh);
 
     // ------------------------------------------------------------------------------------------ general path
     if (!done) {
@@ -1033,22 +1110,7 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
         __syncthreads();
     }
 
-    // ------------------------------------------------------------------------------------------ resume state and tail
-    if (cnt > sd.chain_cap) { if (tid == 0) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CHAIN_FULL); cnt = sd.chain_cap; }
-    int64_t keep_from = fin_fresh ? fin_pos : fin_pos - FX_HOP;
-    keep_from = max(-st_in.carry_len, min(keep_from, sd.n));
-    const int64_t keep = sd.n - keep_from;
-    const bool overflow = keep > sd.carry_cap;
-    if (!overflow)
-        for (int64_t i = tid; i < keep; i += NT) sd.carry_out_end[i - keep] = xld(xs, keep_from + i);
-    if (tid == 0) {
-        FxStreamState so;
-        so.pos = fin_pos - sd.n; so.floor = max(fin_floor - sd.n, -keep); so.carry_len = keep; so.fresh = fin_fresh ? 1u : 0u;
-        so.invalid = overflow ? 1u : 0u; so.overflow = overflow ? 1u : 0u; so.pad_ = 0;
-        *sd.state_out = so; *sd.state_out_host = so;
-        chain_count[s] = cnt;
-        if (overflow) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CARRY_OVERFLOW);
-    }
+    chain_finish<NT>(sd, s, st_in, cnt, fin_pos, fin_floor, fin_fresh, chain_count, hdr);
 }
 
 extern "C" hipError_t fx_launch_chain(unsigned mode, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
@@ -1069,7 +1131,8 @@ extern "C" hipError_t fx_launch_chain(unsigned mode, unsigned nstreams, hipStrea
 // (stream order, then position -- the order results are reported in), the matched-filter work items, the PLL lists (one per
 // modulation class, each padded to whole waves) and the two decode lists (with / without a Reed-Solomon stage).  It also
 // writes one FxOutRec per frame straight into pinned host memory and mirrors the block header there.
-#define PLAN_THREADS 1024
+#define PLAN_THREADS 256
+#define PLAN_NV 6
 
 __device__ __forceinline__ unsigned pll_class(unsigned ms)
 {
@@ -1080,29 +1143,37 @@ __device__ __forceinline__ unsigned pll_class(unsigned ms)
     }
 }
 
-// exclusive scan of one value per thread over the workgroup (PLAN_THREADS threads); returns the prefix, `total` on all threads
-__device__ __forceinline__ uint32_t plan_scan(uint32_t v, uint32_t *ws, uint32_t &total)
+// exclusive scan of PLAN_NV values per thread over the workgroup, in one go (two barriers); v[] -> prefixes, tot[] -> totals
+__device__ __forceinline__ void plan_scan(uint32_t (&v)[PLAN_NV], uint32_t (&tot)[PLAN_NV], uint32_t (*ws)[PLAN_NV])
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t inc = v;
+    uint32_t inc[PLAN_NV];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += o; }
-    __syncthreads();
-    if (lane == 63) ws[wave] = inc;
-    __syncthreads();
-    uint32_t wb = 0, tot = 0;
+    for (int q = 0; q < PLAN_NV; q++) {
+        inc[q] = v[q];
 #pragma unroll
-    for (int w = 0; w < PLAN_THREADS / 64; w++) { const uint32_t t = ws[w]; if (w < wave) wb += t; tot += t; }
-    total = tot;
-    return wb + inc - v;
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)inc[q], d, 64); if (lane >= d) inc[q] += o; }
+    }
+    __syncthreads();
+    if (lane == 63) for (int q = 0; q < PLAN_NV; q++) ws[wave][q] = inc[q];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < PLAN_NV; q++) {
+        uint32_t wb = 0, t = 0;
+#pragma unroll
+        for (int w = 0; w < PLAN_THREADS / 64; w++) { const uint32_t x = ws[w][q]; if (w < wave) wb += x; t += x; }
+        tot[q] = t; v[q] = wb + inc[q] - v[q];
+    }
 }
 
+// hdr: the block's walk-phase counters (zeroed again at the end, for the slot's next block); hdr_pay: what the payload kernels
+// read; hdr_host: the host's copy.
 extern "C" __global__ __launch_bounds__(PLAN_THREADS)
 void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
                     uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                    uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_host)
+                    uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host)
 {
-    __shared__ uint32_t ws[PLAN_THREADS / 64];
+    __shared__ uint32_t ws[PLAN_THREADS / 64][PLAN_NV];
     __shared__ uint32_t cls_cnt[FX_PLL_CLASSES], cls_base[FX_PLL_CLASSES + 1], cls_fill[FX_PLL_CLASSES], dec_cnt[2], dec_fill[2];
     const int tid = threadIdx.x;
     if (tid < FX_PLL_CLASSES) { cls_cnt[tid] = 0; cls_fill[tid] = 0; }
@@ -1111,10 +1182,10 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     uint32_t run = 0;
     for (uint32_t s0 = 0; s0 < nstreams; s0 += PLAN_THREADS) {
         const uint32_t sidx = s0 + tid;
-        const uint32_t c = sidx < nstreams ? chain_count[sidx] : 0u;
-        uint32_t tot; const uint32_t pre = plan_scan(c, ws, tot);
-        if (sidx < nstreams) stream_base[sidx] = run + pre;
-        run += tot;
+        uint32_t v[PLAN_NV] = { sidx < nstreams ? chain_count[sidx] : 0u, 0, 0, 0, 0, 0 }, tot[PLAN_NV];
+        plan_scan(v, tot, ws);
+        if (sidx < nstreams) stream_base[sidx] = run + v[0];
+        run += tot[0];
     }
     const uint32_t N = run;
     if (tid == 0) stream_base[nstreams] = N;
@@ -1124,58 +1195,59 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     for (uint32_t g0 = 0; g0 < N; g0 += PLAN_THREADS) {
         const uint32_t g = g0 + tid;
         const bool live = g < N;
-        FxFrame f; uint32_t sidx = 0;
-        uint32_t sym_sz = 0, byte_sz = 0, dw_sz = 0, out_sz = 0, nblk = 0, bps = 0, k = 0, l0 = 0, l1 = 0;
+        const FxFrame *fp = chain; uint32_t sidx = 0;
+        uint32_t v[PLAN_NV] = { 0, 0, 0, 0, 0, 0 }, tot[PLAN_NV], bps = 0, k = 0, l0 = 0, l1 = 0, nblk = 0;
         bool valid = false;
         if (live) {
             uint32_t lo = 0, hi = nstreams;                                  // stream_base[lo] <= g < stream_base[hi]
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (stream_base[mid] <= g) lo = mid; else hi = mid; }
             sidx = lo;
-            f = chain[streams[sidx].chain_base + (g - stream_base[sidx])];
-            valid = !detect && (f.flags & FX_FLAG_HEADER_VALID);
+            fp = chain + streams[sidx].chain_base + (g - stream_base[sidx]);
+            valid = !detect && (fp->flags & FX_FLAG_HEADER_VALID);
             if (valid) {
-                bps = modem_bps(f.ms);
-                k = f.pay_len + crc_len(f.check); l0 = fec_enc_len(f.fec0, k); l1 = fec_enc_len(f.fec1, l0);
-                sym_sz = (f.pay_sym_len + 7u) & ~7u;                         // 8-symbol granules: 64-byte block I/O in the PLL kernel
-                byte_sz = (max(l1, k) + 8u + 15u) & ~15u;
-                dw_sz = ((8u * max(l0, k) + 6u + 63u) & ~63u) + 64u;          // whole 64-step chunks, lane-major
-                out_sz = (f.pay_len + 15u) & ~15u;
-                nblk = (f.pay_sym_len + 1023u) / 1024u;
+                const uint32_t nsym = fp->pay_sym_len, plen = fp->pay_len;
+                bps = modem_bps(fp->ms);
+                k = plen + crc_len(fp->check); l0 = fec_enc_len(fp->fec0, k); l1 = fec_enc_len(fp->fec1, l0);
+                nblk = (nsym + 1023u) / 1024u;
+                v[0] = (nsym + 7u) & ~7u;                                   // 8-symbol granules: 64-byte block I/O in the PLL kernel
+                v[1] = (max(l1, k) + 8u + 15u) & ~15u;
+                v[2] = ((8u * max(l0, k) + 6u + 63u) & ~63u) + 64u;          // whole 64-step chunks, lane-major
+                v[3] = (plen + 15u) & ~15u;
+                v[4] = nblk; v[5] = 1u;
             }
         }
-        uint32_t t0, t1, t2, t3, t4, t5;
-        const uint32_t sym_off = sym_run + plan_scan(sym_sz, ws, t0);
-        const uint32_t byte_off = byte_run + plan_scan(byte_sz, ws, t1);
-        const uint32_t dw_off = dw_run + plan_scan(dw_sz, ws, t2);
-        const uint32_t out_off = out_run + plan_scan(out_sz, ws, t3);
-        const uint32_t mf_off = mf_run + plan_scan(nblk, ws, t4);
-        (void)plan_scan(valid ? 1u : 0u, ws, t5);
-        sym_run += t0; byte_run += t1; dw_run += t2; out_run += t3; mf_run += t4; npj += t5;
+        plan_scan(v, tot, ws);
+        const uint32_t sym_off = sym_run + v[0], byte_off = byte_run + v[1], dw_off = dw_run + v[2], out_off = out_run + v[3], mf_off = mf_run + v[4];
+        sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; npj += tot[5];
         if (live) {
             const FxStreamDesc &sd = streams[sidx];
             FxPayJob j;
-            j.x = sd.x; j.xa_end = sd.xa_end; j.start = f.start; j.mix_th = f.mix_th; j.mix_dl = f.mix_dl; j.mf_scale = f.mf_scale;
-            j.pfb = f.pfb; j.mfc0 = f.mfc0; j.pll_th = f.pll_th; j.pll_f = f.pll_f; j.ms = f.ms; j.bps = bps;
-            j.nsym = valid ? f.pay_sym_len : 0u; j.sym_off = sym_off;
-            j.pay_len = f.pay_len; j.check = f.check; j.fec0 = f.fec0; j.fec1 = f.fec1; j.k = k; j.l0 = l0; j.l1 = l1;
+            j.x = sd.x; j.xa_end = sd.xa_end; j.start = fp->start; j.mix_th = fp->mix_th; j.mix_dl = fp->mix_dl; j.mf_scale = fp->mf_scale;
+            j.pfb = fp->pfb; j.mfc0 = fp->mfc0; j.pll_th = fp->pll_th; j.pll_f = fp->pll_f; j.ms = fp->ms; j.bps = bps;
+            j.nsym = valid ? fp->pay_sym_len : 0u; j.sym_off = sym_off;
+            j.pay_len = fp->pay_len; j.check = fp->check; j.fec0 = fp->fec0; j.fec1 = fp->fec1; j.k = k; j.l0 = l0; j.l1 = l1;
             j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = valid ? 1u : 0u;
             pjobs[g] = j;
-            FxOutRec r;
-            r.start = sd.abs_base + f.start; r.stream = sidx; r.offset = f.offset;
-            r.rxy = f.rxy; r.tau = f.tau; r.gamma = f.gamma; r.dphi = f.dphi; r.phi = f.phi; r.pfb = f.pfb;
-            r.pilot_dphi = f.pilot_dphi; r.pilot_phi = f.pilot_phi; r.pilot_gain = f.pilot_gain;
-            r.flags = f.flags & FX_FLAG_HEADER_VALID;
-            r.pay_len = valid ? f.pay_len : 0u; r.ms = f.ms; r.check = f.check; r.fec0 = f.fec0; r.fec1 = f.fec1;
-            r.nsym = valid ? f.pay_sym_len : 0u; r.bps = bps; r.sym_off = sym_off; r.out_off = out_off;
-            r.evm_sum = 0.0f; r.payload_valid = 0; r.status = 0;
+            // the record goes to pinned host memory: assemble it in registers, send it as eight 16-byte stores
+            union { FxOutRec r; uint4 q[sizeof(FxOutRec) / 16]; } u;
+            u.r.start = sd.abs_base + fp->start; u.r.stream = sidx; u.r.offset = fp->offset;
+            u.r.rxy = fp->rxy; u.r.tau = fp->tau; u.r.gamma = fp->gamma; u.r.dphi = fp->dphi; u.r.phi = fp->phi; u.r.pfb = fp->pfb;
+            u.r.pilot_dphi = fp->pilot_dphi; u.r.pilot_phi = fp->pilot_phi; u.r.pilot_gain = fp->pilot_gain;
+            u.r.flags = fp->flags & FX_FLAG_HEADER_VALID;
+            u.r.pay_len = valid ? fp->pay_len : 0u; u.r.ms = fp->ms; u.r.check = fp->check; u.r.fec0 = fp->fec0; u.r.fec1 = fp->fec1;
+            u.r.nsym = valid ? fp->pay_sym_len : 0u; u.r.bps = bps; u.r.sym_off = sym_off; u.r.out_off = out_off;
+            u.r.evm_sum = 0.0f; u.r.payload_valid = 0; u.r.status = 0;
+            const uint32_t *hw = reinterpret_cast<const uint32_t *>(fp->header); uint32_t *rw = reinterpret_cast<uint32_t *>(u.r.header);
 #pragma unroll
-            for (int i = 0; i < FX_HDR_DEC; i++) r.header[i] = f.header[i];
-            r.pad_[0] = 0;
-            recs[g] = r;
+            for (int i = 0; i < FX_HDR_DEC / 4; i++) rw[i] = hw[i];
+            u.r.pad_[0] = 0;
+            uint4 *dst = reinterpret_cast<uint4 *>(recs + g);
+#pragma unroll
+            for (int i = 0; i < (int)(sizeof(FxOutRec) / 16); i++) dst[i] = u.q[i];
             if (valid) {
                 for (uint32_t c = 0; c < nblk; c++) if (mf_off + c < mf_cap) { mf_job[mf_off + c] = g; mf_c0[mf_off + c] = c * 1024u; }
-                atomicAdd(&cls_cnt[pll_class(f.ms)], 1u);
-                atomicAdd(&dec_cnt[(f.fec0 == FX_FEC_RS_M8 || f.fec1 == FX_FEC_RS_M8) ? 1 : 0], 1u);
+                atomicAdd(&cls_cnt[pll_class(fp->ms)], 1u);
+                atomicAdd(&dec_cnt[(fp->fec0 == FX_FEC_RS_M8 || fp->fec1 == FX_FEC_RS_M8) ? 1 : 0], 1u);
             }
         }
     }
@@ -1201,26 +1273,30 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
         if (dp < list_cap) dec_list[(size_t)rs * list_cap + dp] = g;
     }
     __syncthreads();
-    // 4. block header, device copy and host mirror
+    // 4. block header: for the payload kernels, for the host; the walk-phase counters are zeroed for the slot's next block
     if (tid == 0) {
         FxBlockHdr h = *hdr;
         h.n_frames = N; h.n_pjobs = npj; h.n_mfblk = min(mf_run, mf_cap); h.n_dec_plain = dec_cnt[0]; h.n_dec_rs = dec_cnt[1];
         for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = cls_cnt[c]; h.pll_base[c] = cls_base[c]; }
         h.pll_base[FX_PLL_CLASSES] = cls_base[FX_PLL_CLASSES];
         h.sym_total = sym_run; h.byte_total = byte_run; h.dw_total = dw_run; h.out_total = out_run;
-        h.done = 0;
-        *hdr = h;
         h.done = 1;
+        *hdr_pay = h;
         *hdr_host = h;
+    }
+    __syncthreads();
+    {
+        uint32_t *z = reinterpret_cast<uint32_t *>(hdr);
+        for (int i = tid; i < (int)(sizeof(FxBlockHdr) / 4); i += PLAN_THREADS) z[i] = 0u;
     }
 }
 
 extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
                                      uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_host)
+                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host)
 {
     hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0, mf_cap,
-                       pll_list, dec_list, list_cap, hdr, hdr_host);
+                       pll_list, dec_list, list_cap, hdr, hdr_pay, hdr_host);
     return hipGetLastError();
 }
 
@@ -1310,7 +1386,8 @@ __device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const fl
             const float a = horiz ? r.x : r.y, b = horiz ? r.y : -r.x;
             pr = neg ? -a : a; pim = neg ? -b : b;
         }
-        pe = atan2c(pim, pr);
+        (void)pr;
+        pe = pim;                                                   // imag(r conj(xhat))
         return gray_enc(idx);
     } else {
         return modem_demod((unsigned)MS, modem_bps((unsigned)MS), r, prev, sc, xh, pe);
@@ -1335,18 +1412,25 @@ __device__ __forceinline__ void pll_frame(uint32_t f, const FxPayJob *jobs, cons
         if (b + 1 < nblk) pll_load8(in + 4 * (b + 1), nxt);
         const unsigned live = min(PLL_BLK, (int)(nsym - b * PLL_BLK));          // < 8 only in the last block
         float rr[2 * PLL_BLK]; unsigned h0 = 0, h1 = 0;
+        // the carrier phasor: from the table at the head of every block of eight, turned by the phase increment in between
+        // (the table look-up is off the symbol-to-symbol recurrence)
+        float wc, ws; sincos_u32(th, sc, wc, ws);
 #pragma unroll
         for (int k = 0; k < PLL_BLK; k++) {
             const float4 v4 = cur[k >> 1];
             const float2 y = (k & 1) ? make_float2(v4.z, v4.w) : make_float2(v4.x, v4.y);
-            float2 r = derot(y, th, sc), xh; float pe;
+            float2 r = make_float2(fmaf(y.x, wc, y.y * ws), fmaf(y.y, wc, -(y.x * ws))), xh; float pe;
             unsigned pv = prev;
             const unsigned s = pll_demod<MS>(r, pv, sc, xh, pe);
             if ((unsigned)k < live) {                                          // tail of the last block: state frozen
                 float dr = r.x - xh.x, di = r.y - xh.y;
                 evm += fmaf(dr, dr, di * di);
                 fq = fmaf(pe, 68356.5248f, fq);                                // alpha = 1e-4 (x 2^32/2pi)
-                th += phase_inc(pe * 6835652.5f) + phase_inc(fq);              // beta = 1e-2 (x 2^32/2pi), then advance
+                const uint32_t inc = phase_inc(pe * 6835652.5f) + phase_inc(fq);   // beta = 1e-2 (x 2^32/2pi), then advance
+                th += inc;
+                float cd, sd; sincos_small(inc, cd, sd);
+                const float c2 = fmaf(wc, cd, -(ws * sd)), s2 = fmaf(ws, cd, wc * sd);
+                wc = c2; ws = s2;
                 prev = pv;
             }
             rr[2 * k] = r.x; rr[2 * k + 1] = r.y;
@@ -1870,19 +1954,11 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 // workgroups keep a block's decode waves together on few CUs instead of sprinkling one wave over every CU, which
 // matters to the walker of the next block (its workgroups need a whole, empty register file each).
 #define DEC_MAX_WAVES 8
+// one frame, one wave
 template <bool WITH_RS>
-__global__ __launch_bounds__(WITH_RS ? DEC_THREADS : DEC_THREADS * DEC_MAX_WAVES)
-void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA,
-                      uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+__device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard, uint8_t *bufA,
+                                          uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
 {
-    __builtin_amdgcn_s_setprio(2);
-    // the list's length is known on the device only: the grid covers the list's capacity and surplus waves leave at once
-    // (a grid-stride loop around this body doubles its register footprint)
-    const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : hdr->n_dec_plain;
-    const uint32_t ji = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    if (ji >= njobs) return;
-    const int lane = threadIdx.x & 63;
-    {
     const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
     // one wave per frame: pin the loop bounds into SGPRs so that every loop below is scalar-controlled
@@ -1957,18 +2033,38 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
         }
     }
     FX_STAMP(5);
+}
+
+template <bool WITH_RS>
+__global__ __launch_bounds__(WITH_RS ? DEC_THREADS : DEC_THREADS * DEC_MAX_WAVES)
+void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, const uint8_t *hard, uint8_t *bufA,
+                      uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+{
+    // The list's length is known on the device only.  The lean instance has no loop around its body (a grid-stride loop
+    // doubles the register footprint): the host launches it over the list's capacity -- a grid sized from the previous block
+    // plus a second, normally idle one for the rest -- and surplus waves leave at once.  The Reed-Solomon instance strides.
+    const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : hdr->n_dec_plain;
+    const uint32_t wpg = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const uint32_t ji0 = __builtin_amdgcn_readfirstlane(first_wave + blockIdx.x * wpg + (threadIdx.x >> 6));
+    if (ji0 >= njobs) return;
+    __builtin_amdgcn_s_setprio(2);
+    if constexpr (WITH_RS) {
+        for (uint32_t ji = ji0; ji < njobs; ji += gridDim.x * wpg) dec_frame<true>(ji, lane, jobs, job_idx, hard, bufA, bufB, dw_arena, out, recs, res, T);
+    } else {
+        dec_frame<false>(ji0, lane, jobs, job_idx, hard, bufA, bufB, dw_arena, out, recs, res, T);
     }
 }
 
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
-                                       const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
-                                       FxOutRec *recs, FxPayResult *res, const FxTables *T)
+extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
+                                       const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena,
+                                       uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
 {
     if (grid_waves == 0) return hipSuccess;
     const unsigned w = with_rs ? 1u : (waves_per_wg < 1u ? 1u : (waves_per_wg > DEC_MAX_WAVES ? DEC_MAX_WAVES : waves_per_wg));
     const dim3 grid((grid_waves + w - 1) / w), block(DEC_THREADS * w);
-    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, grid, block, 0, st, jobs, job_idx, hdr, hard, bufA, bufB, dw_arena, out, recs, res, T);
-    else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, hdr, hard, bufA, bufB, dw_arena, out, recs, res, T);
+    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, dw_arena, out, recs, res, T);
+    else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, dw_arena, out, recs, res, T);
     return hipGetLastError();
 }
 

@@ -80,6 +80,7 @@ void     fxr_init(void);                        /* builds all shared tables once
 uint32_t fxr_rad2u32(float rad);                /* rintf(rad * 2^32/2pi) wrapped mod 2^32 */
 uint32_t fxr_phase_inc(float units);            /* rintf(units) clamped below 2^31: PLL increments in phase units */
 void     fxr_sincos_u32(uint32_t th, float *c, float *s);
+void     fxr_sincos_small(uint32_t inc, float *c, float *s);   /* 5th-order series: cos/sin of a small signed phase increment */
 float    fxr_atan2(float y, float x);
 float    fxr_sum_tree(const float *v, unsigned n);          /* n power of two */
 fxr_c32  fxr_csum_tree(const fxr_c32 *v, unsigned n);       /* n power of two */
@@ -120,7 +121,7 @@ unsigned fxr_modem_bps(int ms);                 /* 0 = unsupported */
 typedef struct { int ms; unsigned bps; float dpsk_phi; } fxr_modem;
 void     fxr_modem_init(fxr_modem *q, int ms);
 fxr_c32  fxr_modem_mod(fxr_modem *q, unsigned sym);
-/* hard demod: returns symbol, writes remodulated point xhat and phase error arg(r conj(xhat)) */
+/* hard demod: returns symbol, writes remodulated point xhat and phase error imag(r conj(xhat)) */
 unsigned fxr_modem_demod(fxr_modem *q, fxr_c32 r, fxr_c32 *xhat, float *phase_err);
 unsigned fxr_qpm_sym_len(unsigned n, int check, int fec0, int fec1, int ms);
 

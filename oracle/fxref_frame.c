@@ -285,6 +285,7 @@ struct fxr_sync {
     /* payload */
     unsigned pay_len, pay_sym_len; int check, fec0, fec1, ms;
     fxr_modem demod; uint32_t pll_th; float pll_f; float evm_sum;
+    float pll_c, pll_s;         /* carrier phasor exp(j pll_th), re-read from the table every 8th symbol, turned incrementally in between */
     fxr_c32 *pay_sym; uint8_t *pay_hard; uint8_t *pay_dec; unsigned pay_cap;
     unsigned pay_counter;
 };
@@ -448,14 +449,24 @@ static void sync_on_symbol(fxr_sync *q, fxr_c32 y)
         if (c == FXR_SYM0_PAY - 1) sync_decode_header(q);
         return;
     }
-    /* payload: decision-directed 2nd-order PLL, alpha = 1e-4, beta = sqrt(alpha) */
-    fxr_c32 r = derot(y, q->pll_th), xh; float pe;
+    /* payload: decision-directed 2nd-order PLL, alpha = 1e-4, beta = sqrt(alpha) [RECALLED nco_crcf_pll_step: frequency +=
+     * alpha * error, phase += beta * error, then nco step], error = imag(r conj(xhat)).  The carrier phasor is read from the
+     * sin/cos table at every 8th symbol and turned by the (integer) phase increment in between -- a GPU-friendly canonical
+     * form: the table look-up leaves the symbol-to-symbol recurrence. */
+    if ((q->pay_counter & 7u) == 0) fxr_sincos_u32(q->pll_th, &q->pll_c, &q->pll_s);
+    fxr_c32 r = { fmaf(y.re, q->pll_c, y.im * q->pll_s), fmaf(y.im, q->pll_c, -(y.re * q->pll_s)) }, xh; float pe;
     unsigned s = fxr_modem_demod(&q->demod, r, &xh, &pe);
     float dr = r.re - xh.re, di = r.im - xh.im;
     q->evm_sum += fmaf(dr, dr, di * di);
     /* loop filter kept in phase units: alpha = 1e-4 and beta = 1e-2 pre-multiplied by 2^32/2pi */
     q->pll_f = fmaf(pe, 68356.5248f, q->pll_f);
-    q->pll_th += fxr_phase_inc(pe * 6835652.5f) + fxr_phase_inc(q->pll_f);
+    uint32_t inc = fxr_phase_inc(pe * 6835652.5f) + fxr_phase_inc(q->pll_f);
+    q->pll_th += inc;
+    {
+        float cd, sd; fxr_sincos_small(inc, &cd, &sd);
+        float c2 = fmaf(q->pll_c, cd, -(q->pll_s * sd)), s2 = fmaf(q->pll_s, cd, q->pll_c * sd);
+        q->pll_c = c2; q->pll_s = s2;
+    }
     q->pay_sym[q->pay_counter] = r; q->pay_hard[q->pay_counter] = (uint8_t)s;
     if (++q->pay_counter == q->pay_sym_len) sync_decode_payload(q);
 }

@@ -137,10 +137,8 @@ unsigned fxr_modem_demod(fxr_modem *q, fxr_c32 r, fxr_c32 *xhat, float *phase_er
     }
     if (xhat) *xhat = xh;
     if (phase_err) {
-        /* r * conj(xhat) */
-        float pr = fmaf(r.re, xh.re, r.im * xh.im);
-        float pi = fmaf(r.im, xh.re, -(r.re * xh.im));
-        *phase_err = fxr_atan2(pi, pr);
+        /* [RECALLED liquid modem_get_demodulator_phase_error]: imag(r * conj(xhat)), not its argument */
+        *phase_err = fmaf(r.im, xh.re, -(r.re * xh.im));
     }
     return sym;
 }

@@ -1,6 +1,5 @@
 """GPU parity tests for the corners of the exact-speculation machinery: frames with no gap,
-overlapping frames, a valid preamble right behind a broken header, traffic dense enough to overflow a walk job's frame
-table -- each over several segment sizes (so that segment boundaries fall everywhere) and against the sequential oracle."""
+overlapping frames, a valid preamble right behind a broken header, the densest possible traffic -- each over several segment sizes (so that segment boundaries fall everywhere) and against the sequential oracle."""
 import numpy as np
 import pytest
 from parity_util import oracle_frames, compare_frames
@@ -79,8 +78,8 @@ def test_valid_frame_close_behind_a_broken_header(fx, oracle):
 
 @pytest.mark.parametrize("plen", [0, 7, 16])
 def test_dense_tiny_frames_overflow_the_frame_table(fx, oracle, plen):
-    """Header-only and tiny-payload frames are ~650-760 samples long: more detections per segment than a walk job has
-    frame-table slots (seg/2048 + 8), so every segment runs through the table-full continuation."""
+    """Header-only and tiny-payload frames are ~630-680 samples long: the densest traffic there is.  (Walk jobs' frame
+    tables are sized for exactly this, one slot per 600 samples of segment.)"""
     rng = np.random.default_rng(33 + plen)
     g = fx.FrameGen(mod=29, fec0=1)                                 # QAM64, no FEC: shortest frames
     parts, p = [], 100
@@ -91,7 +90,6 @@ def test_dense_tiny_frames_overflow_the_frame_table(fx, oracle, plen):
     x = _chan(_place(parts), 0.004, -0.4, 30.0, rng)
     of, reps = _check(fx, oracle, x, segs=(0, 8192, 40000, 1 << 18), min_frames=400)
     assert sum(f.payload_valid for f in of) >= 400
-    assert reps > 0, "the table-full continuation was never taken"
 
 
 def test_dense_traffic_across_speculative_blocks(fx, oracle):
