@@ -73,10 +73,16 @@ FX_DEV void sincos_u32(uint32_t th, const float2 *sc, float &c, float &s)
     s = fmaf(t.y, cd, t.x * sd);
 }
 
-// cos / sin of a small signed phase increment, 5th-order series (payload PLL: turns the carrier phasor between table look-ups)
-FX_DEV void sincos_small(uint32_t inc, float &c, float &s)
+// payload PLL: the phase advance of one symbol, in whole phase units (rounded, clamped below 2^31 so that the conversion
+// to an integer is the same everywhere), and the cos / sin of that advance by a 5th-order series -- the loop turns its
+// carrier phasor by this between table look-ups
+FX_DEV float phase_step(float units)
 {
-    float x  = (float)(int)inc * 1.4629180792671596e-9f;
+    return fminf(fmaxf(rintf(units), -2147483520.0f), 2147483520.0f);
+}
+FX_DEV void sincos_small(float step_units, float &c, float &s)
+{
+    float x  = step_units * 1.4629180792671596e-9f;
     float x2 = x * x;
     c = fmaf(x2, fmaf(x2, 4.16666679e-2f, -0.5f), 1.0f);
     s = fmaf(x * x2, fmaf(x2, 8.33333377e-3f, -0.16666667f), x);

@@ -149,6 +149,7 @@ struct Slot {
     fxrx_timing timing{};
     double host_submit_ms = 0.0;
     bool any_late = false;
+    uint32_t kept_hops = 0, kept_cheap = 0, kept_vhops = 0, kept_vfail = 0;   // walk-phase counters of a block whose back part was run again
 };
 
 struct fxrx_ctx_s {
@@ -531,6 +532,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     const unsigned nslots = c->depth + 1;
     Slot &sl = *c->slots[c->head];
     sl.out.clear(); sl.timing = fxrx_timing{};
+    sl.kept_hops = sl.kept_cheap = sl.kept_vhops = sl.kept_vfail = 0;
     sl.seq = c->seq;
     sl.x.assign(NS, nullptr); sl.n.assign(n_samples, n_samples + NS); sl.snap.assign(NS, StreamSnap{});
     if (sl.d_in.size() < NS) sl.d_in.resize(NS);
@@ -576,6 +578,8 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
         const uint32_t flags = sl.h_hdr.p->flags;
         if (flags & FX_BLK_NEEDS_REPAIR) {
             c->repairs_host++;
+            const FxBlockHdr &h0 = *sl.h_hdr.p;         // the walk-phase counters are zeroed with the first plan kernel: keep them
+            sl.kept_hops += h0.hops; sl.kept_cheap += h0.hops_cheap; sl.kept_vhops += h0.verify_hops; sl.kept_vfail += h0.verify_failures;
             if (enqueue_back(c, sl, true)) return FXRX_ERR_HIP;
             continue;                                   // (its tail may in turn overflow the carry buffer)
         }
@@ -677,8 +681,8 @@ int fxrx_collect(fxrx_ctx *c)
         (void)hipEventElapsedTime(&ms, sl.ev[6], sl.ev[7]); t.paydec_ms = ms;
     }
     t.total_ms = t.walk_ms + t.seekverify_ms + t.chain_ms + t.paymf_ms + t.paypll_ms + t.paydec_ms;
-    t.hops = h.hops; t.hops_cheap = h.hops_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs; t.frames = h.n_frames;
-    t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops; t.verify_failures = h.verify_failures;
+    t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs; t.frames = h.n_frames;
+    t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops + sl.kept_vhops; t.verify_failures = h.verify_failures + sl.kept_vfail;
     t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays + c->repairs_host;
     sl.busy = false; c->last = &sl;
     c->tail = (c->tail + 1) % nslots; c->inflight--;
@@ -711,6 +715,8 @@ static int walk_stamps(const fxrx_ctx *c, uint64_t sum[4], uint64_t maxjob[8])
 #endif
     return 0;
 }
+// shader clocks of the chain kernel's phases (stream 0) of the last collected block: whole fast path, -, pointer chase, kernel total
+int fxrx_debug_chain_stamps(const fxrx_ctx *c, uint32_t out[8]) { if (!c || !c->last) return FXRX_ERR_ARG; std::memcpy(out, c->last->h_hdr.p->stamp, 8 * sizeof(uint32_t)); return 0; }
 int fxrx_debug_walk_stamps(const fxrx_ctx *c, uint64_t out[4]) { if (!c) return FXRX_ERR_ARG; uint64_t mj[8]; return walk_stamps(c, out, mj); }
 int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]) { if (!c) return FXRX_ERR_ARG; uint64_t sm[4]; return walk_stamps(c, sm, out); }
 

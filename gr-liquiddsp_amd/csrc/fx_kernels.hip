@@ -828,13 +828,16 @@ extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const 
 //     tail go to where the next block's true walker will look for them.
 // Fast path (no repair needed anywhere, at most CHAIN_MAXJ segments): hand-off look-ups for all segments in parallel,
 // a pointer chase through LDS, parallel compaction.  Anything else takes the general sequential loop below it.
-#define CHAIN_MAXJ 2048
+#define CHAIN_MAXJ 1024
 #define CHAIN_NONE 4095u
 
 struct ChainLds {
-    uint32_t lk[CHAIN_MAXJ], info[CHAIN_MAXJ], base[CHAIN_MAXJ];
-    float    rxy[CHAIN_MAXJ];
-    uint16_t m[CHAIN_MAXJ], pred[CHAIN_MAXJ], skip[CHAIN_MAXJ];
+    uint32_t lk[CHAIN_MAXJ + 1];        // successor segment (11 bits) | index of the hand-off target in its list (12 bits, CHAIN_NONE: not there)
+    uint32_t info[CHAIN_MAXJ + 1];      // frames | exact frames << 12 | exit code << 24 | has hand-off << 27 | tail span bad << 28 | too many frames << 29
+    uint32_t P[CHAIN_MAXJ + 1];         // frames the chain holds up to and including this segment's (minus the first segment's own)
+    uint32_t accA[CHAIN_MAXJ + 1], accB[CHAIN_MAXJ + 1];
+    uint16_t skip[CHAIN_MAXJ + 1], m[CHAIN_MAXJ + 1], pred[CHAIN_MAXJ + 1], jumpA[CHAIN_MAXJ + 1], jumpB[CHAIN_MAXJ + 1];
+    uint8_t  markA[CHAIN_MAXJ + 1], markB[CHAIN_MAXJ + 1];
     uint32_t sh[8];
 };
 
@@ -848,14 +851,19 @@ __device__ __forceinline__ void copy_frame(FxFrame *dst, const FxFrame *src)
 }
 
 // Fast path of the chain (nothing to repair, at most CHAIN_MAXJ segments): returns false when the general path is needed.
+//   A. every segment, in parallel: its own summary and the look-up of its hand-off target in the list it points at;
+//   B. which segments are on the chain, and how many frames the chain holds before each: the segments form a linked list
+//      (first -> successor -> ...), ranked by pointer doubling in LDS -- log2(segments) rounds instead of a pointer chase;
+//   C. compaction, one thread per segment on the chain.
 template <int NT>
 __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const FxWalkJob *jobs, const FxWalkResult *results, const FxFrame *frames, FxFrame *out,
                                                 ChainLds &C, uint32_t &cnt, int64_t &fin_pos, int64_t &fin_floor, bool &fin_fresh)
 {
     const int tid = threadIdx.x;
-    const uint32_t first = sd.first_job, nj = sd.n_jobs;
+    const uint32_t first = sd.first_job, nj = sd.n_jobs, T = nj;           // T: the list's end marker
     if (nj > CHAIN_MAXJ) return false;
-    // A. every segment: its own summary and the look-up of its hand-off target in the list it points at
+    if (tid < 8) C.sh[tid] = 0;
+    // A.
     for (uint32_t j = tid; j < nj; j += NT) {
         const FxWalkResult &R = results[first + j];
         const FxFrame *F = frames + jobs[first + j].frame_base;
@@ -863,8 +871,8 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
         if (ex == FX_EXIT_PAYLOAD && nf > 0) nf--;
         uint32_t cntE = 0;
         for (uint32_t i = 0; i < nf; i++) cntE += (F[i].flags & FX_FLAG_EXACT) ? 1u : 0u;
-        C.info[j] = nf | (cntE << 12) | (ex << 24) | ((R.has_handoff ? 1u : 0u) << 27) | (((R.tail_flags & FX_FLAG_SPAN_BAD) ? 1u : 0u) << 28) | ((nf >= CHAIN_NONE ? 1u : 0u) << 29);
-        C.rxy[j] = R.handoff_rxy;
+        C.info[j] = (nf & 4095u) | ((cntE & 4095u) << 12) | (ex << 24) | ((R.has_handoff ? 1u : 0u) << 27) | (((R.tail_flags & FX_FLAG_SPAN_BAD) ? 1u : 0u) << 28) |
+                    ((nf >= CHAIN_NONE ? 1u : 0u) << 29);
         uint32_t lk = CHAIN_NONE << 11, skipE = 0;
         if (R.has_handoff && ex == FX_EXIT_STOP && j + 1 < nj) {
             uint32_t nxt = j + 1;
@@ -881,45 +889,77 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
             }
             lk = nxt | (found << 11);
         }
-        C.lk[j] = lk; C.skip[j] = (uint16_t)skipE; C.m[j] = 0xFFFFu;
+        C.lk[j] = lk; C.skip[j] = (uint16_t)skipE; C.m[j] = 0xFFFFu; C.pred[j] = 0xFFFFu;
     }
     __syncthreads();
-    // B. the chain itself: a pointer chase through LDS
-    if (tid == 0) {
-        uint32_t cur = 0, m = 0, base = 0, skipE = 0, pred = 0xFFFFu, problem = 0, endjob = 0, end_nothing = 0;
-        bool spliced = false;
-        for (;;) {
-            const uint32_t inf = C.info[cur], nf = inf & 4095u, cntE = (inf >> 12) & 4095u, ex = (inf >> 24) & 7u;
-            C.m[cur] = (uint16_t)(m | (spliced ? 0x8000u : 0u)); C.base[cur] = base; C.pred[cur] = (uint16_t)pred;
-            base += cntE - skipE;
-            const bool nothing = spliced && nf <= m;
-            if ((inf >> 29) & 1u) { problem = 1; break; }
-            if (!nothing && ((inf >> 28) & 1u)) { problem = 1; break; }            // a skipped hop of its tail seek fires
-            if (ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID) { problem = 1; break; }
-            if (cur + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u)) { endjob = cur; end_nothing = nothing ? 1u : 0u; break; }
-            const uint32_t lk = C.lk[cur], found = (lk >> 11) & 4095u;
-            if (found == CHAIN_NONE) { problem = 1; break; }                        // target not in the next list: repair
-            pred = cur; spliced = true; m = found; skipE = C.skip[cur]; cur = lk & 2047u;
+    // B. list ranking.  Edge j -> nxt carries the number of frames nxt contributes when entered from j.
+    for (uint32_t j = tid; j <= nj; j += NT) {
+        uint32_t jmp = T, w = 0;
+        if (j < nj) {
+            const uint32_t inf = C.info[j], ex = (inf >> 24) & 7u, lk = C.lk[j];
+            const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
+            if (!term && ((lk >> 11) & 4095u) != CHAIN_NONE) { jmp = lk & 2047u; w = ((C.info[jmp] >> 12) & 4095u) - C.skip[j]; }
         }
-        C.sh[0] = problem; C.sh[1] = endjob; C.sh[2] = end_nothing; C.sh[3] = base;
-        if (base > sd.chain_cap) C.sh[0] = 1;
+        C.jumpA[j] = (uint16_t)jmp; C.accA[j] = w; C.markA[j] = j == 0 ? 1 : 0; C.markB[j] = j == 0 ? 1 : 0; C.P[j] = 0;
     }
     __syncthreads();
-    // C. compaction, one thread per segment on the chain
+    {
+        uint16_t *jr = C.jumpA, *jw = C.jumpB; uint32_t *ar = C.accA, *aw = C.accB; uint8_t *mr = C.markA, *mw = C.markB;
+        for (uint32_t span = 1; span < nj; span <<= 1) {
+            for (uint32_t j = tid; j <= nj; j += NT) {
+                const uint32_t k = jr[j];
+                if (mr[j] && k != T) { mw[k] = 1; C.P[k] = C.P[j] + ar[j]; }       // nodes at distance [span, 2 span) from the head
+                jw[j] = jr[k]; aw[j] = ar[j] + ar[k];
+            }
+            __syncthreads();
+            for (uint32_t j = tid; j <= nj; j += NT) mr[j] = mw[j];
+            __syncthreads();
+            uint16_t *tj = jr; jr = jw; jw = tj; uint32_t *ta = ar; ar = aw; aw = ta;
+        }
+        // every segment on the chain tells its successor how it is entered
+        for (uint32_t j = tid; j < nj; j += NT) {
+            if (!mr[j]) continue;
+            const uint32_t inf = C.info[j], ex = (inf >> 24) & 7u, lk = C.lk[j], found = (lk >> 11) & 4095u;
+            const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
+            if (!term && found != CHAIN_NONE) { const uint32_t k = lk & 2047u; C.m[k] = (uint16_t)(found | 0x8000u); C.pred[k] = (uint16_t)j; }
+            if (j == 0) C.m[0] = 0;
+        }
+        __syncthreads();
+        // problems, the chain's end, frame offsets
+        const uint32_t c0 = (C.info[0] >> 12) & 4095u;
+        for (uint32_t j = tid; j < nj; j += NT) {
+            if (!mr[j]) continue;
+            const uint32_t inf = C.info[j], nf = inf & 4095u, ex = (inf >> 24) & 7u, cm = C.m[j], m = cm & 0x7FFFu, lk = C.lk[j];
+            const bool spliced = (cm & 0x8000u) != 0, nothing = spliced && nf <= m;
+            const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
+            bool problem = ((inf >> 29) & 1u) || ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID;
+            if (!nothing && ((inf >> 28) & 1u)) problem = true;                        // a skipped hop of its tail seek fires
+            if (!term && ((lk >> 11) & 4095u) == CHAIN_NONE) problem = true;           // target not in the next list: repair
+            if (problem) C.sh[0] = 1;
+            const uint32_t contrib = j == 0 ? c0 : ((inf >> 12) & 4095u) - C.skip[C.pred[j]];
+            const uint32_t upto = c0 + C.P[j];                                         // frames up to and including this segment's
+            C.accA[j] = upto - contrib;                                                // (accA is free now: offset of its first frame)
+            if (term || problem) { C.sh[1] = j; C.sh[2] = nothing ? 1u : 0u; C.sh[3] = upto; }
+        }
+        __syncthreads();
+        if (tid == 0 && C.sh[3] > sd.chain_cap) C.sh[0] = 1;
+        __syncthreads();
+    }
+    // C.
     if (!C.sh[0]) {
         for (uint32_t j = tid; j < nj; j += NT) {
             const uint32_t cm = C.m[j];
             if (cm == 0xFFFFu) continue;
             const uint32_t m = cm & 0x7FFFu, nf = C.info[j] & 4095u; const bool spliced = (cm & 0x8000u) != 0;
             const FxFrame *F = frames + jobs[first + j].frame_base;
-            uint32_t o = C.base[j];
+            uint32_t o = C.accA[j];
             for (uint32_t i = m; i < nf; i++) {
                 const uint32_t fl = F[i].flags;
                 if (!(fl & FX_FLAG_EXACT)) continue;
                 const bool own = !(spliced && i == m);
                 if (own && (fl & FX_FLAG_SPAN_BAD)) C.sh[0] = 1;
                 copy_frame(out + o, F + i);
-                if (!own) out[o].rxy = C.rxy[C.pred[j]];                            // coarse peak as the true chain saw it
+                if (!own) out[o].rxy = results[first + C.pred[j]].handoff_rxy;          // coarse peak as the true chain saw it
                 o++;
             }
         }
@@ -987,7 +1027,9 @@ void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, con
     FxStreamState st_in;
     if (!chain_state_in(sd, s, st_in, chain_count, hdr)) return;
     uint32_t cnt = 0; int64_t fin_pos = 0, fin_floor = 0; bool fin_fresh = true;
+    const unsigned long long t0_ = __builtin_readcyclecounter();
     const bool ok = !force_repair && chain_fast_path<CHAINFAST_THREADS>(sd, jobs, results, frames, chain + sd.chain_base, C, cnt, fin_pos, fin_floor, fin_fresh);
+    if (s == 0 && threadIdx.x == 0) { hdr->stamp[0] = (uint32_t)(__builtin_readcyclecounter() - t0_); }
     if (!ok) {
         if (threadIdx.x == 0) {
             FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
@@ -997,6 +1039,7 @@ void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, con
         return;
     }
     chain_finish<CHAINFAST_THREADS>(sd, s, st_in, cnt, fin_pos, fin_floor, fin_fresh, chain_count, hdr);
+    if (s == 0 && threadIdx.x == 0) hdr->stamp[3] = (uint32_t)(__builtin_readcyclecounter() - t0_);
 }
 
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
@@ -1394,6 +1437,42 @@ __device__ __forceinline__ unsigned pll_demod(float2 r, unsigned &prev, const fl
     }
 }
 
+// One block of eight symbols.  TAIL: the frame's last block, where only `live` symbols count (the others are padding of
+// the 8-symbol granule: rotated and stored, but the loop state and the EVM sum stay frozen).
+template <int MS, bool TAIL>
+__device__ __forceinline__ void pll_block8(const float4 (&cur)[4], unsigned live, uint32_t &th, float &fq, float &evm, unsigned &prev, const float2 *sc,
+                                           float4 *out, uint2 *hd)
+{
+    float rr[2 * PLL_BLK]; unsigned h0 = 0, h1 = 0;
+    // the carrier phasor: from the table at the head of every block of eight, turned by the phase increment in between
+    // (the table look-up is off the symbol-to-symbol recurrence)
+    float wc, ws; sincos_u32(th, sc, wc, ws);
+#pragma unroll
+    for (int k = 0; k < PLL_BLK; k++) {
+        const float4 v4 = cur[k >> 1];
+        const float2 y = (k & 1) ? make_float2(v4.z, v4.w) : make_float2(v4.x, v4.y);
+        float2 r = make_float2(fmaf(y.x, wc, y.y * ws), fmaf(y.y, wc, -(y.x * ws))), xh; float pe;
+        unsigned pv = prev;
+        const unsigned s = pll_demod<MS>(r, pv, sc, xh, pe);
+        if (!TAIL || (unsigned)k < live) {
+            float dr = r.x - xh.x, di = r.y - xh.y;
+            evm += fmaf(dr, dr, di * di);
+            fq = fmaf(pe, 68356.5248f, fq);                                // alpha = 1e-4 (x 2^32/2pi): frequency
+            const float t = phase_step(fmaf(pe, 6835652.5f, fq));          // beta = 1e-2 (x 2^32/2pi): phase, then advance; whole phase units
+            th += (uint32_t)(int)t;
+            float cd, sd; sincos_small(t, cd, sd);
+            const float c2 = fmaf(wc, cd, -(ws * sd)), s2 = fmaf(ws, cd, wc * sd);
+            wc = c2; ws = s2;
+            prev = pv;
+        }
+        rr[2 * k] = r.x; rr[2 * k + 1] = r.y;
+        if (k < 4) h0 |= s << (8 * k); else h1 |= s << (8 * (k - 4));
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[k] = make_float4(rr[4 * k], rr[4 * k + 1], rr[4 * k + 2], rr[4 * k + 3]);
+    *hd = make_uint2(h0, h1);
+}
+
 template <int MS>
 __device__ __forceinline__ void pll_frame(uint32_t f, const FxPayJob *jobs, const float2 *sc, const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs)
 {
@@ -1405,43 +1484,16 @@ __device__ __forceinline__ void pll_frame(uint32_t f, const FxPayJob *jobs, cons
     // loop state: phase (2^32 = one turn), frequency in the same units per symbol, EVM accumulator
     uint32_t th = job.pll_th; float fq = job.pll_f * 683565248.0f, evm = 0.0f; unsigned prev = 0;
     const unsigned nsym = job.nsym;
-    const uint32_t nblk = (nsym + PLL_BLK - 1) / PLL_BLK;
+    const uint32_t nfull = nsym / PLL_BLK, rem = nsym % PLL_BLK;
     float4 cur[4], nxt[4];
-    if (nblk) pll_load8(in, cur);
-    for (uint32_t b = 0; b < nblk; b++) {
-        if (b + 1 < nblk) pll_load8(in + 4 * (b + 1), nxt);
-        const unsigned live = min(PLL_BLK, (int)(nsym - b * PLL_BLK));          // < 8 only in the last block
-        float rr[2 * PLL_BLK]; unsigned h0 = 0, h1 = 0;
-        // the carrier phasor: from the table at the head of every block of eight, turned by the phase increment in between
-        // (the table look-up is off the symbol-to-symbol recurrence)
-        float wc, ws; sincos_u32(th, sc, wc, ws);
-#pragma unroll
-        for (int k = 0; k < PLL_BLK; k++) {
-            const float4 v4 = cur[k >> 1];
-            const float2 y = (k & 1) ? make_float2(v4.z, v4.w) : make_float2(v4.x, v4.y);
-            float2 r = make_float2(fmaf(y.x, wc, y.y * ws), fmaf(y.y, wc, -(y.x * ws))), xh; float pe;
-            unsigned pv = prev;
-            const unsigned s = pll_demod<MS>(r, pv, sc, xh, pe);
-            if ((unsigned)k < live) {                                          // tail of the last block: state frozen
-                float dr = r.x - xh.x, di = r.y - xh.y;
-                evm += fmaf(dr, dr, di * di);
-                fq = fmaf(pe, 68356.5248f, fq);                                // alpha = 1e-4 (x 2^32/2pi)
-                const uint32_t inc = phase_inc(pe * 6835652.5f) + phase_inc(fq);   // beta = 1e-2 (x 2^32/2pi), then advance
-                th += inc;
-                float cd, sd; sincos_small(inc, cd, sd);
-                const float c2 = fmaf(wc, cd, -(ws * sd)), s2 = fmaf(ws, cd, wc * sd);
-                wc = c2; ws = s2;
-                prev = pv;
-            }
-            rr[2 * k] = r.x; rr[2 * k + 1] = r.y;
-            if (k < 4) h0 |= s << (8 * k); else h1 |= s << (8 * (k - 4));
-        }
-#pragma unroll
-        for (int k = 0; k < 4; k++) out[4 * b + k] = make_float4(rr[4 * k], rr[4 * k + 1], rr[4 * k + 2], rr[4 * k + 3]);
-        hd[b] = make_uint2(h0, h1);
+    if (nsym) pll_load8(in, cur);
+    for (uint32_t b = 0; b < nfull; b++) {
+        if ((b + 1) * PLL_BLK < nsym) pll_load8(in + 4 * (b + 1), nxt);
+        pll_block8<MS, false>(cur, PLL_BLK, th, fq, evm, prev, sc, out + 4 * b, hd + b);
 #pragma unroll
         for (int k = 0; k < 4; k++) cur[k] = nxt[k];
     }
+    if (rem) pll_block8<MS, true>(cur, rem, th, fq, evm, prev, sc, out + 4 * nfull, hd + nfull);
     recs[f].evm_sum = evm;                                                          // straight into the host's result record
 }
 

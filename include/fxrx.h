@@ -182,6 +182,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
 int fxrx_collect(fxrx_ctx *c);
 /* diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases of payload job i */
 int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8]);
+int fxrx_debug_chain_stamps(const fxrx_ctx *c, uint32_t out[8]);  /* chain kernel phase clocks (stream 0) of the last collected block */
 int fxrx_debug_walk_stamps(const fxrx_ctx *c, uint64_t out[4]);   /* summed walker phase clocks: coarse, seek, align, header */
 int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]);   /* slowest walk job: 4 phase clocks, hops, coarse hops, frames, total */
 /* device-resident payload symbols / hard decisions of the last call (NULL if none) */

@@ -80,7 +80,8 @@ void     fxr_init(void);                        /* builds all shared tables once
 uint32_t fxr_rad2u32(float rad);                /* rintf(rad * 2^32/2pi) wrapped mod 2^32 */
 uint32_t fxr_phase_inc(float units);            /* rintf(units) clamped below 2^31: PLL increments in phase units */
 void     fxr_sincos_u32(uint32_t th, float *c, float *s);
-void     fxr_sincos_small(uint32_t inc, float *c, float *s);   /* 5th-order series: cos/sin of a small signed phase increment */
+float    fxr_phase_step(float units);            /* rintf(units) clamped below 2^31: the PLL's phase advance per symbol */
+void     fxr_sincos_small(float step_units, float *c, float *s);   /* 5th-order series: cos/sin of that advance */
 float    fxr_atan2(float y, float x);
 float    fxr_sum_tree(const float *v, unsigned n);          /* n power of two */
 fxr_c32  fxr_csum_tree(const fxr_c32 *v, unsigned n);       /* n power of two */

@@ -460,10 +460,10 @@ static void sync_on_symbol(fxr_sync *q, fxr_c32 y)
     q->evm_sum += fmaf(dr, dr, di * di);
     /* loop filter kept in phase units: alpha = 1e-4 and beta = 1e-2 pre-multiplied by 2^32/2pi */
     q->pll_f = fmaf(pe, 68356.5248f, q->pll_f);
-    uint32_t inc = fxr_phase_inc(pe * 6835652.5f) + fxr_phase_inc(q->pll_f);
-    q->pll_th += inc;
+    float step = fxr_phase_step(fmaf(pe, 6835652.5f, q->pll_f));
+    q->pll_th += (uint32_t)(int32_t)step;
     {
-        float cd, sd; fxr_sincos_small(inc, &cd, &sd);
+        float cd, sd; fxr_sincos_small(step, &cd, &sd);
         float c2 = fmaf(q->pll_c, cd, -(q->pll_s * sd)), s2 = fmaf(q->pll_s, cd, q->pll_c * sd);
         q->pll_c = c2; q->pll_s = s2;
     }

@@ -61,11 +61,19 @@ void fxr_sincos_u32(uint32_t th, float *c, float *s)
     *s = fmaf(t.im, cd, t.re * sd);
 }
 
-/* cos / sin of a small signed phase increment (phase units, 2^32 = one turn), 5th-order series: the payload PLL turns its
- * carrier phasor by this per symbol instead of looking the whole phase up again (fxref_frame.c: sync_on_symbol) */
-void fxr_sincos_small(uint32_t inc, float *c, float *s)
+/* payload PLL: the phase advance of one symbol in whole phase units (2^32 = one turn; rounded, clamped below 2^31 so that
+ * the conversion to an integer is the same everywhere), and cos / sin of that advance by a 5th-order series: the loop turns
+ * its carrier phasor by this per symbol instead of looking the whole phase up again (fxref_frame.c: sync_on_symbol) */
+float fxr_phase_step(float units)
 {
-    float x  = (float)(int32_t)inc * 1.4629180792671596e-9f;         /* 2 pi / 2^32 */
+    float t = rintf(units);
+    if (t < -2147483520.0f) t = -2147483520.0f;
+    if (t > 2147483520.0f) t = 2147483520.0f;
+    return t;
+}
+void fxr_sincos_small(float step_units, float *c, float *s)
+{
+    float x  = step_units * 1.4629180792671596e-9f;                  /* 2 pi / 2^32 */
     float x2 = x * x;
     *c = fmaf(x2, fmaf(x2, 4.16666679e-2f, -0.5f), 1.0f);
     *s = fmaf(x * x2, fmaf(x2, 8.33333377e-3f, -0.16666667f), x);

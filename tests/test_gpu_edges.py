@@ -116,3 +116,34 @@ def test_dense_traffic_across_speculative_blocks(fx, oracle):
     while inflight:
         got += ctx.results(ctx.collect_raw()); inflight -= 1
     compare_frames(of, got)
+
+
+def test_repairs_with_blocks_in_flight_behind_them(fx, oracle):
+    """Weak preambles around the detector's threshold make skipped hops fire under verification (and hand-off targets go
+    missing): the lean chain kernel leaves such a block unstitched, fxrx_collect has the full-size chain kernel walk the
+    stretch again -- and the blocks already in flight behind it, which found no state to start from, are enqueued again.
+    Continuing blocks, three in flight, against the sequential oracle."""
+    rng = np.random.default_rng(2026)
+    g = fx.FrameGen()
+    parts = [np.zeros(300, np.complex64)]
+    for k in range(260):
+        amp = 1.0 if k % 7 == 0 else rng.uniform(0.16, 0.5)
+        parts += [amp * g.frame(rng.integers(0, 256, 64, dtype=np.uint8)), np.zeros(int(rng.integers(300, 3000)), np.complex64)]
+    g.close()
+    x = _chan(np.concatenate(parts), 0.013, 0.9, 12.0, rng)
+    of = oracle_frames(oracle, x)
+    assert len(of) > 150
+    nb = 8
+    cuts = [len(x) * k // nb for k in range(nb + 1)]
+    ctx = fx.RxContext(1, want_framesyms=True, segment_len=16384)
+    ctx.set_depth(3)
+    keep = [np.ascontiguousarray(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    got, inflight, fails = [], 0, 0
+    for pc in keep:
+        if inflight == 3:
+            got += ctx.results(ctx.collect_raw()); fails += ctx.timing()["verify_failures"]; inflight -= 1
+        ctx.submit_raw([pc.ctypes.data], [len(pc)], False); inflight += 1
+    while inflight:
+        got += ctx.results(ctx.collect_raw()); fails += ctx.timing()["verify_failures"]; inflight -= 1
+    compare_frames(of, got)
+    assert fails > 0 and ctx.timing()["replays"] > 0, "no block needed a repair: the path was not exercised"
