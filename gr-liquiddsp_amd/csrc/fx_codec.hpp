@@ -66,6 +66,18 @@ inline void design_arkaiser(unsigned k, unsigned m, float beta_f, float dt, floa
     for (unsigned i = 0; i < n; i++) h[i] = (float)(hd[i] * g);
 }
 
+// initial taps of the optional equaliser: Kaiser-windowed sinc low-pass (13 taps, fc = 0.4, As = 40 dB) scaled by 2 fc
+inline void design_eq_init(float *h /* 13 */)
+{
+    const unsigned n = 13; const double fc = 0.4, kb = 0.5842 * std::pow(40.0 - 21.0, 0.4) + 0.07886 * (40.0 - 21.0);
+    for (unsigned i = 0; i < n; i++) {
+        double t = (double)i - (double)(n - 1) / 2.0, xs = 2.0 * fc * t;
+        double sn = std::fabs(xs) < 1e-12 ? 1.0 : std::sin(M_PI * xs) / (M_PI * xs);
+        double r = 2.0 * t / (double)n, a = 1.0 - r * r;
+        h[i] = (float)(sn * (bessel_i0(kb * std::sqrt(a > 0 ? a : 0)) / bessel_i0(kb)) * 2.0 * fc);
+    }
+}
+
 // ------------------------------------------------------------------ host FFT-512 (same 8x8x8 network as the kernel)
 namespace hfft {
 inline cf add(cf a, cf b) { return { a.re + b.re, a.im + b.im }; }

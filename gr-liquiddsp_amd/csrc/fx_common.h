@@ -30,6 +30,9 @@
 #define FX_PROTOCOL      102
 #define FX_SYM0_HDR      78      /* 2m + 64 */
 #define FX_SYM0_PAY      309
+#define FX_EQ_TAPS       13      /* optional equaliser: 2 k p + 1 taps at 2 samples/symbol, p = 3 */
+#define FX_EQ_DELAY      3       /* its delay: every symbol instant moves this many symbols later */
+#define FX_EQ_MU         0.05f
 
 // Waves per workgroup of the detector kernels (4 or 8).  8 halves the latency of a detector hop (49 CFO-sweep
 // transforms in 7 rounds instead of 13): right for the dense detector-only walker.  The flex_rx
@@ -110,9 +113,11 @@ struct FxWalkJob {
     const FxStreamState *state_in;   // non-NULL: true walker of a continuing stream: start / floor / fresh come from here
     uint32_t stream;
     uint32_t verify_per;    // hops per verification run
+    uint32_t eq;            // 1: equaliser stage on (fxrx_config.equalizer)
+    uint32_t pad_;
 };
 
-struct FxFrame {            // 152 bytes
+struct FxFrameHead {        // 152 bytes: everything the walker keeps in registers while it builds a frame record
     int64_t  start;         // index of aligned sample 0 (may be < floor: zeros there)
     int64_t  next;          // restart position after this frame (flex_rx) / next new-half (detect)
     int64_t  seek_pos, seek_floor;   // the seek that led here started at this hop / with this floor ...
@@ -126,6 +131,9 @@ struct FxFrame {            // 152 bytes
     uint32_t flags;
     uint32_t pay_len, ms, check, fec0, fec1, pay_sym_len;
     uint8_t  header[FX_HDR_DEC];
+};
+struct FxFrame : FxFrameHead {   // 256 bytes
+    float2   eq[FX_EQ_TAPS];    // equaliser taps after training on the p/n symbols (equaliser stage on; else untouched)
 };
 
 struct FxWalkResult {
@@ -251,7 +259,9 @@ struct FxPayJob {           // one per chain frame; nsym == 0: no payload stage 
     uint32_t byte_off;      // offset of this frame's scratch in the byte arenas (stride >= l1+8)
     uint32_t dw_off;        // offset in the decision-word arena (u64 units)
     uint32_t out_off;       // offset of decoded payload in the output arena
-    uint32_t pad_;
+    uint32_t pad_;          // 1: the frame has a payload stage
+    uint32_t eq;            // 1: equaliser on: taps at chain[chain_idx].eq, symbol instants FX_EQ_DELAY later
+    uint32_t chain_idx;     // the frame's slot in the chain table
 };
 
 struct FxPayResult {        // diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases

@@ -15,10 +15,12 @@ struct FxTables {
     float2   s[FX_S_LEN];    // detector template (RRC-shaped p/n preamble)
     float2   TD[512];        // FFT of td[k] = s[k+1] conj(s[k]) (coarse pre-lock scan only)
     float2   pilots[16];
+    float2   pn[FX_PN_LEN];  // the 64 p/n preamble symbols (equaliser training)
     float    proto[FX_PROTO_LEN + 3];
     float    s2sum;          // sum |s|^2
     float    td2sum;         // sum |td|^2
     float    pad_[2];
+    float    eq0[16];        // initial equaliser taps (13, real)
     uint16_t perm54[FX_HDR_ENC * 8];   // bit gather tables of the header de-interleavers
     uint16_t perm27[FX_HDR_E0 * 8];
     uint8_t  h84dec[256];
@@ -277,6 +279,20 @@ FX_DEV unsigned modem_demod(unsigned ms, unsigned bps, float2 r, unsigned &dpsk_
     }
     pe = fmaf(r.y, xh.x, -(r.x * xh.y));          // imag(r conj(xhat))
     return sym;
+}
+
+// equaliser output: sum over the 13 taps of x[i] conj(w[i]), in the balanced-tree order of a 16-lane xor butterfly
+// (slots 13..15 are zeros; the additions of zero are kept, they are part of the canonical order)
+FX_DEV float2 eq_sum16(const float2 *x, const float2 *w)
+{
+    float2 p[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) p[i] = i < FX_EQ_TAPS ? cmulc(x[i], w[i]) : make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int st = 1; st < 16; st <<= 1)
+#pragma unroll
+        for (int i = 0; i < 16; i += 2 * st) p[i] = cadd(p[i], p[i + st]);
+    return p[0];
 }
 
 // sample index (relative to the aligned start) at which MF output symbol c appears

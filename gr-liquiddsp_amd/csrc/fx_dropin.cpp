@@ -23,7 +23,7 @@ struct HeldFrame {
 // ------------------------------------------------------------------------------------------ flexframesync
 struct fxrx_sync_s {
     framesync_callback cb = nullptr; void *ud = nullptr;
-    fxrx_ctx *ctx = nullptr;
+    fxrx_ctx *ctx = nullptr; float threshold = 0.0f; int equalizer = 0;
     std::vector<fx_complex> queue; unsigned block = 1u << 16;
     std::deque<HeldFrame> pending; HeldFrame current;
 
@@ -93,18 +93,20 @@ void fxrx_sync_flush(flexframesync q) { if (!q) return; if (!q->queue.empty()) (
 void fxrx_sync_set_block(flexframesync q, unsigned int samples) { if (q) q->block = samples ? samples : 1; }
 unsigned int fxrx_sync_pending(flexframesync q) { return q ? (unsigned)q->pending.size() : 0; }
 unsigned int fxrx_sync_errors(flexframesync q) { return q ? q->errors : 0; }
-void fxrx_sync_set_threshold(flexframesync q, float t)
+// threshold and equaliser live in the context configuration: make a new context first, swap only if that worked (state is
+// reset, as liquid's setters do not promise otherwise); on failure the old context stays and the error is reported
+static void sync_recreate(flexframesync q, const char *what)
 {
-    // the threshold lives in the context configuration: make a new context first, swap only if that worked (state is
-    // reset, as liquid's setter does not promise otherwise); on failure the old context stays and the error is reported
-    if (!q) return;
-    fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1; cfg.threshold = t;
+    fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1;
+    cfg.threshold = q->threshold; cfg.equalizer = q->equalizer;
     if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
     fxrx_ctx *nc = fxrx_create(&cfg);
-    if (!nc) { q->errors++; std::fprintf(stderr, "libfxrx: fxrx_sync_set_threshold: %s (threshold unchanged)\n", fxrx_last_error()); return; }
+    if (!nc) { q->errors++; std::fprintf(stderr, "libfxrx: %s: %s (setting unchanged)\n", what, fxrx_last_error()); return; }
     fxrx_destroy(q->ctx);
     q->ctx = nc;
 }
+void fxrx_sync_set_threshold(flexframesync q, float t) { if (!q) return; q->threshold = t; sync_recreate(q, "fxrx_sync_set_threshold"); }
+void fxrx_sync_set_equalizer(flexframesync q, int on) { if (!q) return; q->equalizer = on ? 1 : 0; sync_recreate(q, "fxrx_sync_set_equalizer"); }
 
 }  // extern "C"
 

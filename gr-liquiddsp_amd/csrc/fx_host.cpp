@@ -39,20 +39,20 @@
 #include "fx_device.h"
 #include "fx_codec.hpp"
 
-extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
+extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
                                      FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T);
 extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results,
                                            FxFrame *frames, FxBlockHdr *hdr, const FxTables *T);
-extern "C" hipError_t fx_launch_chain(unsigned mode, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
+extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
                                       FxWalkResult *results, FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap,
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T);
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
                                           const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair);
-extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
+extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, const FxFrame *chain, const uint32_t *chain_count,
                                      uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                                      uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host);
-extern "C" hipError_t fx_launch_paymf(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
-                                      float2 *sym_raw, const FxTables *T);
+extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
+                                      const FxFrame *chain, float2 *sym_raw, const FxTables *T);
 extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs, const FxTables *T);
 extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
@@ -184,6 +184,8 @@ int upload_tables(fxrx_ctx_s *c)
     for (int i = 0; i < 1024; i++) t->sc[i] = make_float2(H.sc[i].re, H.sc[i].im);
     for (int i = 0; i < FX_S_LEN; i++) t->s[i] = make_float2(H.s[i].re, H.s[i].im);
     for (int i = 0; i < FX_HDR_PILOTS; i++) t->pilots[i] = make_float2(H.pilots[i].re, H.pilots[i].im);
+    for (int i = 0; i < FX_PN_LEN; i++) t->pn[i] = make_float2(H.pn[i].re, H.pn[i].im);
+    fx::design_eq_init(t->eq0);
     std::memcpy(t->proto, H.proto, sizeof H.proto);
     t->s2sum = H.s2sum;
     {   // differential template for the speculative walkers' coarse scan
@@ -393,7 +395,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
             j.threshold = c->cfg.threshold;
             j.no_skip = (detect || !c->skip_seek) ? 1u : 0u;
             j.state_in = (first && cont) ? sd.state_in : nullptr;
-            j.stream = s; j.verify_per = c->verify_per;
+            j.stream = s; j.verify_per = c->verify_per; j.eq = (!detect && c->cfg.equalizer) ? 1u : 0u;
             (first && cont ? late : early).push_back((uint32_t)jobs.size());
             jobs.push_back(j);
             p = j.stop; first = false;
@@ -444,11 +446,11 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     // ---- 3. the chain, front part: walkers and seek verification ----
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(sl.ev[0], st));
-    HIP_OK(fx_launch_walk(mode, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
+    HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
     // the true walkers of continuing streams read the state the previous block's chain kernel leaves
     if (!late.empty()) {
         if (c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
-        HIP_OK(fx_launch_walk(mode, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
     }
     HIP_OK(hipEventRecord(sl.ev[1], st));
     if (!detect && c->skip_seek)
@@ -475,20 +477,20 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
     const uint32_t chain_slots = sl.chain_cap, list_cap = chain_slots + 64 * FX_PLL_CLASSES;
     FxBlockHdr *hdr = sl.d_hdr.p, *hdr_pay = sl.d_hdr.p + 1;
     if (full)
-        HIP_OK(fx_launch_chain(mode, NS, st, d_streams, d_jobs, (uint32_t)sl.NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
+        HIP_OK(fx_launch_chain(mode, c->cfg.equalizer ? 1 : 0, NS, st, d_streams, d_jobs, (uint32_t)sl.NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
                                hdr, c->chain_slow ? 1u : 0u, c->d_tables));
     else
         HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u));
     HIP_OK(hipEventRecord(sl.ev[3], st));
     c->prev_chain = sl.ev[3];
-    HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
+    HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
                           sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap, hdr, hdr_pay, sl.h_hdr.p));
     HIP_OK(hipEventRecord(sl.ev[4], st));
     if (!detect) {
         // grids stride over lists whose lengths only the device knows; size them from what the last block held
         const uint64_t fh = c->frames_hint ? std::min<uint64_t>(chain_slots, c->frames_hint + c->frames_hint / 2 + 64) : chain_slots;
         const unsigned mf_grid = (unsigned)std::min<uint64_t>(sl.mf_cap, 8ull * (uint64_t)c->n_cus);
-        HIP_OK(fx_launch_paymf(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_symraw.p, c->d_tables));
+        HIP_OK(fx_launch_paymf(mf_grid, c->cfg.equalizer ? 1 : 0, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_chain.p, sl.d_symraw.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[5], st));
         c->carry_reader[b % 3] = sl.ev[5];
         HIP_OK(fx_launch_paypll((unsigned)(fh / 64 + FX_PLL_CLASSES), c->pll_waves, st, sl.d_pjobs.p, sl.d_pll_list.p, hdr_pay, sl.d_symraw.p, sl.d_framesyms.p,

@@ -37,6 +37,7 @@ template <int WW> struct WalkLdsT {
     float2 hdr[FX_HDR_SYM];
     float2 cw[(WW + 1) * FX_HOP + 8];   // coarse scan: overlap half + one new hop per wave
     float2 pb[16];                  // de-rotated pilots
+    float2 eqw[16];                 // equaliser taps (equaliser stage on)
     float  taps[FX_MF_TAPS];
     float  redf[WW < 4 ? 4 : WW]; float2 redc[WW < 4 ? 4 : WW];
     float  redv[WW]; uint32_t redk[WW];
@@ -233,7 +234,7 @@ template <class LDS> __device__ __forceinline__ void decode_header_bytes(LDS &L,
 // One walk: the synchroniser's state machine from (start, floor, fresh) of `job` until the job's stop / hand-off / end of
 // data.  Called by the whole workgroup (fx_walk_kernel: once; fx_chain_kernel: for every repair).  L.S (template spectrum)
 // must be loaded; the result record and the frames go to global memory (thread 0), verification runs to `runs`.
-template <int MODE, int WW>
+template <int MODE, int WW, bool EQ>
 __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_index, FxWalkResult *result, FxFrame *frames, FxVerifyRun *runs,
                                          uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, WalkLdsT<WW> &L,
                                          const float2 (&twA)[7], const float2 (&twB)[7])
@@ -549,7 +550,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         }
 
         WSTAMP(2);
-        FxFrame fr;
+        FxFrameHead fr;
         fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
         fr.seek_pos = span_pos; fr.seek_floor = span_floor; fr.det_pos = pos;
         fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
@@ -571,7 +572,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
             locked = true; fr.flags |= FX_FLAG_EXACT;
             // back to SEEK with the second half of the aligned window as overlap
             fr.next = a0 + FX_NFFT;
-            if (tid == 0) frames[job.frame_base + nfr] = fr;
+            if (tid == 0) static_cast<FxFrameHead &>(frames[job.frame_base + nfr]) = fr;
             nfr++;
             span_pos = a0 + FX_NFFT; span_floor = floor_; span_flags = FX_FLAG_SPAN_EXACT;
             __syncthreads();
@@ -588,21 +589,62 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         if (tau > 0.0f) { fr.pfb = (unsigned)(tau * (float)FX_NPFB) % FX_NPFB; fr.mfc0 = 0; }
         else { fr.pfb = (unsigned)((1.0f + tau) * (float)FX_NPFB) % FX_NPFB; fr.mfc0 = 1; }
         fr.mf_scale = 0.5f / gamma;
-        const int nh = (int)sym_sample(FX_SYM0_PAY - 1, fr.mfc0);      // sample of the last header symbol
+        constexpr int dly = EQ ? FX_EQ_DELAY : 0;                      // the equaliser moves every symbol instant 3 symbols later
+        const int nh = (int)sym_sample(FX_SYM0_PAY + dly - 1, fr.mfc0);  // sample of the last header symbol
         if (a0 + nh + 1 > n) { exit_code = FX_EXIT_NEED_DATA; break; }
         for (int m = tid; m <= nh; m += WALK_THREADS)
             L.v[m] = derot(xv(xs, a0 + m, floor_), fr.mix_th + mix_dl * (uint32_t)m, sc);
         if (tid < FX_MF_TAPS) L.taps[tid] = T->proto[fr.pfb + FX_NPFB * tid];
         __syncthreads();
-        if (tid < FX_HDR_SYM) {
-            const int nc = (int)sym_sample(FX_SYM0_HDR + tid, fr.mfc0);
-            float ar = 0.0f, ai = 0.0f;
+        if (!EQ) {
+            if (tid < FX_HDR_SYM) {
+                const int nc = (int)sym_sample(FX_SYM0_HDR + tid, fr.mfc0);
+                float ar = 0.0f, ai = 0.0f;
 #pragma unroll 4
-            for (int t = 0; t < FX_MF_TAPS; t++) {
-                const float2 w = L.v[nc - t]; const float h = L.taps[t];
-                ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+                for (int t = 0; t < FX_MF_TAPS; t++) {
+                    const float2 w = L.v[nc - t]; const float h = L.taps[t];
+                    ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+                }
+                L.hdr[tid] = make_float2(ar * fr.mf_scale, ai * fr.mf_scale);
             }
-            L.hdr[tid] = make_float2(ar * fr.mf_scale, ai * fr.mf_scale);
+        } else {
+            // Equaliser stage (liquid: FLEXFRAMESYNC_ENABLE_EQ): the matched filter is evaluated at every sample, a 13-tap
+            // eqlms at 2 samples/symbol follows it, trained on the 64 p/n symbols (normalised LMS, mu = 0.05) and frozen
+            // from the header on.  mfo[] (matched-filter outputs of the whole span) borrows the coarse scan's window.
+            float2 *mfo = L.cw;
+            for (int m = tid; m <= nh; m += WALK_THREADS) {
+                float ar = 0.0f, ai = 0.0f;
+#pragma unroll 4
+                for (int t = 0; t < FX_MF_TAPS; t++) {
+                    const float2 w = (m - t >= 0) ? L.v[m - t] : make_float2(0.0f, 0.0f); const float h = L.taps[t];
+                    ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+                }
+                mfo[m] = make_float2(ar * fr.mf_scale, ai * fr.mf_scale);
+            }
+            __syncthreads();
+            if (wave == 0) {                                               // lane i < 13 owns tap i; sums are 16-lane xor butterflies
+                float2 w = lane < FX_EQ_TAPS ? make_float2(T->eq0[lane], 0.0f) : make_float2(0.0f, 0.0f);
+                for (int c = 2 * FX_M + dly; c < FX_SYM0_HDR + dly; c++) {
+                    const int nc = (int)sym_sample(c, fr.mfc0);
+                    const float2 r = lane < FX_EQ_TAPS ? mfo[nc - (FX_EQ_TAPS - 1) + lane] : make_float2(0.0f, 0.0f);
+                    float2 y = cmulc(r, w); float x2 = cm2(r);
+#pragma unroll
+                    for (int mk = 1; mk < 16; mk <<= 1) { y.x += __shfl_xor(y.x, mk, 64); y.y += __shfl_xor(y.y, mk, 64); x2 += __shfl_xor(x2, mk, 64); }
+                    if (x2 > 0.0f) {
+                        const float2 d = T->pn[c - 2 * FX_M - dly];
+                        const float2 e = make_float2(d.x - y.x, d.y - y.y);
+                        const float g = FX_EQ_MU / x2;
+                        const float2 cc = cmulc(r, e);
+                        w.x = fmaf(g, cc.x, w.x); w.y = fmaf(g, cc.y, w.y);
+                    }
+                }
+                if (lane < 16) L.eqw[lane] = w;
+            }
+            __syncthreads();
+            if (tid < FX_HDR_SYM) {
+                const int nc = (int)sym_sample(FX_SYM0_HDR + dly + tid, fr.mfc0);
+                L.hdr[tid] = eq_sum16(mfo + nc - (FX_EQ_TAPS - 1), L.eqw);
+            }
         }
         __syncthreads();
         // pilot sync: 32-point DFT of the 15 de-rotated pilots
@@ -675,7 +717,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         fr.pll_f = pdphi; fr.pll_th = pph + pdl * (uint32_t)FX_HDR_SYM;
 #pragma unroll
         for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = L.b1[j];
-        int64_t last_c = FX_SYM0_PAY - 1;
+        int64_t last_c = FX_SYM0_PAY + dly - 1;
         if (hv) {
             fr.flags |= FX_FLAG_HEADER_VALID;
             fr.pay_len = L.u[2]; fr.ms = L.u[3]; fr.check = L.u[4]; fr.fec0 = L.u[5]; fr.fec1 = L.u[6]; fr.pay_sym_len = L.u[7];
@@ -687,7 +729,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
             // speculative walker, header did not check out: most likely a false alarm on payload data.
             // Do not skip the 618 samples a real invalid frame would consume (a true preamble may sit
             // there); resume seeking on the same grid.  Nothing before the lock is ever spliced.
-            if (tid == 0) frames[job.frame_base + nfr] = fr;
+            if (tid == 0) static_cast<FxFrameHead &>(frames[job.frame_base + nfr]) = fr;
             nfr++;
             __syncthreads();
             if (lo) L.win[tid] = nw;
@@ -700,8 +742,9 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         if (incomplete) fr.flags |= FX_FLAG_INCOMPLETE;
         if (tid == 0) {
             if (!incomplete && emit_runs(fr.det_pos, job.frame_base + nfr)) fr.flags |= FX_FLAG_SPAN_BAD;
-            frames[job.frame_base + nfr] = fr;
+            static_cast<FxFrameHead &>(frames[job.frame_base + nfr]) = fr;
         }
+        if (EQ && tid < FX_EQ_TAPS) frames[job.frame_base + nfr].eq[tid] = L.eqw[tid];
         nfr++;
         if (incomplete) { exit_code = FX_EXIT_PAYLOAD; break; }
         // synchroniser reset: fresh detector right after the frame's last symbol
@@ -731,7 +774,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
     }
 }
 
-template <int MODE, int WW>
+template <int MODE, int WW, bool EQ>
 __global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
 void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
                     FxBlockHdr *hdr, const FxTables *T)
@@ -744,15 +787,17 @@ void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResul
 #pragma unroll
     for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
     for (int i = tid; i < FX_NFFT; i += 64 * WW) L.S[i] = T->S[i];
-    walk_run<MODE, WW>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB);
+    walk_run<MODE, WW, EQ>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB);
 }
 
-extern "C" hipError_t fx_launch_walk(unsigned mode, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
+// (the equaliser stage is a compile-time variant of the flex_rx walker: the default instance carries none of its code)
+extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
                                      FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T)
 {
     if (njobs == 0) return hipSuccess;
-    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_DETECT, FX_DETECT_WAVES>), dim3(njobs), dim3(64 * FX_DETECT_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
-    else hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
+    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_DETECT, FX_DETECT_WAVES, false>), dim3(njobs), dim3(64 * FX_DETECT_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
+    else if (eq) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES, true>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
+    else hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES, false>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
     return hipGetLastError();
 }
 
@@ -1050,7 +1095,7 @@ extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, con
 }
 
 // The full-size chain kernel: same fast path, and behind it the general, sequential one that can walk.
-template <int MODE, int WW>
+template <int MODE, int WW, bool EQ>
 __global__ __launch_bounds__(64 * WW, 1)
 void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total, FxWalkResult *results, FxFrame *frames,
                      FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, uint32_t force_slow,
@@ -1092,7 +1137,7 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
                 j.start = wst; j.floor = wfl; j.fresh = wfr ? 1u : 0u; j.prelock = 0; j.no_skip = 1; j.state_in = nullptr;
                 j.frame_base = sd.repair_base; j.max_frames = sd.repair_cap;
                 __syncthreads();
-                walk_run<MODE, WW>(j, wj, rep_res, frames, runs, run_cap, hdr, T, L, twA, twB);
+                walk_run<MODE, WW, EQ>(j, wj, rep_res, frames, runs, run_cap, hdr, T, L, twA, twB);
                 wg_sync_global();
                 if (tid == 0) atomicAdd(&hdr->repairs, 1u);
                 Rp = rep_res; F = frames + sd.repair_base; m = 0; need_walk = false;
@@ -1109,7 +1154,7 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
                 if (cnt < sd.chain_cap) {
                     const uint32_t *a = reinterpret_cast<const uint32_t *>(F + i); uint32_t *b = reinterpret_cast<uint32_t *>(out + cnt);
                     if (tid < (int)(sizeof(FxFrame) / 4))               // coarse peak of a spliced frame: as the true chain saw it
-                        b[tid] = (!own && tid == (int)(offsetof(FxFrame, rxy) / 4)) ? __builtin_bit_cast(uint32_t, splice_rxy) : a[tid];
+                        b[tid] = (!own && tid == (int)(offsetof(FxFrameHead, rxy) / 4)) ? __builtin_bit_cast(uint32_t, splice_rxy) : a[tid];
                 }
                 cnt++;
             }
@@ -1156,15 +1201,18 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
     chain_finish<NT>(sd, s, st_in, cnt, fin_pos, fin_floor, fin_fresh, chain_count, hdr);
 }
 
-extern "C" hipError_t fx_launch_chain(unsigned mode, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
+extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
                                       FxWalkResult *results, FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap,
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T)
 {
     if (mode == FX_MODE_DETECT)
-        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_DETECT, FX_DETECT_WAVES>), dim3(nstreams), dim3(64 * FX_DETECT_WAVES), 0, st, streams, jobs, n_jobs_total, results,
+        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_DETECT, FX_DETECT_WAVES, false>), dim3(nstreams), dim3(64 * FX_DETECT_WAVES), 0, st, streams, jobs, n_jobs_total, results,
+                           frames, chain, chain_count, runs, run_cap, hdr, force_slow, T);
+    else if (eq)
+        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES, true>), dim3(nstreams), dim3(64 * FX_FLEX_WAVES), 0, st, streams, jobs, n_jobs_total, results,
                            frames, chain, chain_count, runs, run_cap, hdr, force_slow, T);
     else
-        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES>), dim3(nstreams), dim3(64 * FX_FLEX_WAVES), 0, st, streams, jobs, n_jobs_total, results,
+        hipLaunchKernelGGL((fx_chain_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES, false>), dim3(nstreams), dim3(64 * FX_FLEX_WAVES), 0, st, streams, jobs, n_jobs_total, results,
                            frames, chain, chain_count, runs, run_cap, hdr, force_slow, T);
     return hipGetLastError();
 }
@@ -1212,7 +1260,7 @@ __device__ __forceinline__ void plan_scan(uint32_t (&v)[PLAN_NV], uint32_t (&tot
 // hdr: the block's walk-phase counters (zeroed again at the end, for the slot's next block); hdr_pay: what the payload kernels
 // read; hdr_host: the host's copy.
 extern "C" __global__ __launch_bounds__(PLAN_THREADS)
-void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
+void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, const FxFrame *chain, const uint32_t *chain_count,
                     uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host)
 {
@@ -1270,6 +1318,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             j.nsym = valid ? fp->pay_sym_len : 0u; j.sym_off = sym_off;
             j.pay_len = fp->pay_len; j.check = fp->check; j.fec0 = fp->fec0; j.fec1 = fp->fec1; j.k = k; j.l0 = l0; j.l1 = l1;
             j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = valid ? 1u : 0u;
+            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain);
             pjobs[g] = j;
             // the record goes to pinned host memory: assemble it in registers, send it as eight 16-byte stores
             union { FxOutRec r; uint4 q[sizeof(FxOutRec) / 16]; } u;
@@ -1334,11 +1383,11 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     }
 }
 
-extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, const FxFrame *chain, const uint32_t *chain_count,
+extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, const FxFrame *chain, const uint32_t *chain_count,
                                      uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                                      uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host)
 {
-    hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0, mf_cap,
+    hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, eq, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0, mf_cap,
                        pll_list, dec_list, list_cap, hdr, hdr_pay, hdr_host);
     return hipGetLastError();
 }
@@ -1349,11 +1398,17 @@ extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams
 #define PMF_SPAN    (2 * PMF_SYMS + FX_MF_TAPS)
 
 // Work items (frame, first symbol) come from fx_plan_kernel; their number is only known on the device, so the grid is
-// sized from the host's estimate and strides over the list.
-extern "C" __global__ __launch_bounds__(PMF_THREADS)
-void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr, float2 *sym_raw, const FxTables *T)
+// sized from the host's estimate and strides over the list.  EQ: the equaliser stage is on -- the matched filter is
+// evaluated at every sample of the item's span and the frame's 13 trained taps combine 13 of its outputs per symbol.
+template <bool EQ>
+__global__ __launch_bounds__(PMF_THREADS)
+void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr, const FxFrame *chain, float2 *sym_raw,
+                     const FxTables *T)
 {
-    __shared__ float2 v[PMF_SPAN + 4];
+    constexpr int LEAD = EQ ? FX_EQ_TAPS - 1 : 0;
+    __shared__ float2 v[PMF_SPAN + LEAD + 4];
+    __shared__ float2 u[EQ ? 2 * PMF_SYMS + FX_EQ_TAPS : 1];
+    __shared__ float2 eqw[16];
     __shared__ float taps[FX_MF_TAPS];
     const uint32_t nitems = hdr->n_mfblk;
     const int tid = threadIdx.x;
@@ -1362,35 +1417,56 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
         const FxPayJob job = jobs[blk_job[bi]];
         const uint32_t c0 = blk_c0[bi];                            // first payload symbol of this item
         const uint32_t ns = min((uint32_t)PMF_SYMS, job.nsym - c0);
-        const int64_t nlo = sym_sample((int64_t)FX_SYM0_PAY + c0, job.mfc0) - (FX_MF_TAPS - 1);
-        const int64_t nhi = sym_sample((int64_t)FX_SYM0_PAY + c0 + ns - 1, job.mfc0);
+        const int64_t sym0 = (int64_t)FX_SYM0_PAY + (EQ ? FX_EQ_DELAY : 0);
+        const int64_t nlo = sym_sample(sym0 + c0, job.mfc0) - LEAD - (FX_MF_TAPS - 1);
+        const int64_t nhi = sym_sample(sym0 + c0 + ns - 1, job.mfc0);
         const int span = (int)(nhi - nlo + 1);
         const XSrc xs = { job.x, job.xa_end, 0 };
         __syncthreads();
         if (tid < FX_MF_TAPS) taps[tid] = T->proto[job.pfb + FX_NPFB * tid];
+        if (EQ && tid < 16) eqw[tid] = tid < FX_EQ_TAPS ? chain[job.chain_idx].eq[tid] : make_float2(0.0f, 0.0f);
         for (int m = tid; m < span; m += PMF_THREADS) {
-            const int64_t nn = nlo + m;
+            const int64_t nn = nlo + m;                            // (nn >= 0: a payload symbol is hundreds of samples into the frame)
             v[m] = derot(xld(xs, job.start + nn), job.mix_th + job.mix_dl * (uint32_t)nn, sc);
         }
         __syncthreads();
-        for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
-            const int nc = (int)(sym_sample((int64_t)FX_SYM0_PAY + c0 + i, job.mfc0) - nlo);
-            float ar = 0.0f, ai = 0.0f;
+        if (EQ) {
+            const int nu = span - (FX_MF_TAPS - 1);                // matched-filter outputs at samples nlo + 27 ... nhi
+            for (int m = tid; m < nu; m += PMF_THREADS) {
+                float ar = 0.0f, ai = 0.0f;
 #pragma unroll 7
-            for (int t = 0; t < FX_MF_TAPS; t++) {
-                const float2 w = v[nc - t]; const float h = taps[t];
-                ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+                for (int t = 0; t < FX_MF_TAPS; t++) {
+                    const float2 w = v[m + (FX_MF_TAPS - 1) - t]; const float h = taps[t];
+                    ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+                }
+                u[m] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
             }
-            sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
+            __syncthreads();
+            for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
+                const int nc = (int)(sym_sample(sym0 + c0 + i, job.mfc0) - nlo) - (FX_MF_TAPS - 1);   // index of the symbol's sample in u[]
+                sym_raw[(size_t)job.sym_off + c0 + i] = eq_sum16(u + nc - (FX_EQ_TAPS - 1), eqw);
+            }
+        } else {
+            for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
+                const int nc = (int)(sym_sample(sym0 + c0 + i, job.mfc0) - nlo);
+                float ar = 0.0f, ai = 0.0f;
+#pragma unroll 7
+                for (int t = 0; t < FX_MF_TAPS; t++) {
+                    const float2 w = v[nc - t]; const float h = taps[t];
+                    ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+                }
+                sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
+            }
         }
     }
 }
 
-extern "C" hipError_t fx_launch_paymf(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
-                                      float2 *sym_raw, const FxTables *T)
+extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
+                                      const FxFrame *chain, float2 *sym_raw, const FxTables *T)
 {
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(fx_paymf_kernel, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, sym_raw, T);
+    if (eq) hipLaunchKernelGGL(fx_paymf_kernel<true>, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, chain, sym_raw, T);
+    else hipLaunchKernelGGL(fx_paymf_kernel<false>, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, chain, sym_raw, T);
     return hipGetLastError();
 }
 

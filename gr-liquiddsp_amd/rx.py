@@ -34,9 +34,9 @@ def _frame_to_dict(f, copy_syms):
 class RxContext:
     """fxrx_ctx wrapper.  Raises RxError when the library or a HIP device is missing (no fallback)."""
 
-    def __init__(self, n_streams=1, mode=MODE_FLEX_RX, device=0, threshold=0.0, segment_len=0, want_framesyms=False):
+    def __init__(self, n_streams=1, mode=MODE_FLEX_RX, device=0, threshold=0.0, segment_len=0, want_framesyms=False, equalizer=False):
         self.L = _ffi.lib()
-        cfg = _ffi.Config(device, mode, n_streams, threshold, segment_len, 1 if want_framesyms else 0)
+        cfg = _ffi.Config(device, mode, n_streams, threshold, segment_len, 1 if want_framesyms else 0, 1 if equalizer else 0)
         self.h = self.L.fxrx_create(C.byref(cfg))
         if not self.h:
             raise RxError("fxrx_create failed: %s" % self.L.fxrx_last_error().decode())

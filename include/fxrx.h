@@ -73,6 +73,7 @@ void flexframesync_reset(flexframesync q);
 void fxrx_sync_flush(flexframesync q);
 void fxrx_sync_set_block(flexframesync q, unsigned int samples);
 void fxrx_sync_set_threshold(flexframesync q, float threshold);
+void fxrx_sync_set_equalizer(flexframesync q, int on);   /* re-creates the context like fxrx_sync_set_threshold */
 unsigned int fxrx_sync_pending(flexframesync q);     /* completed frames not yet delivered */
 /* the liquid signatures return void: a block that failed on the GPU keeps its samples queued (they run again with the
  * next call), the text stays in fxrx_last_error(), one line goes to stderr and this counter goes up */
@@ -132,6 +133,9 @@ typedef struct {
                                     /root/reference/lib/frame_detector_cc_impl.cc:55) */
     unsigned int segment_len;    /* speculation granularity in samples (0 -> auto) */
     int          want_framesyms; /* copy payload symbols back to the host with each result */
+    int          equalizer;      /* 1: optional equaliser stage on (liquid: FLEXFRAMESYNC_ENABLE_EQ, compiled out of a stock libliquid):
+                                    13-tap eqlms at 2 samples/symbol behind the matched filter, trained on the 64 p/n symbols, frozen
+                                    afterwards; symbol instants move 3 symbols later.  0 (default): what flexframesync executes */
 } fxrx_config;
 
 typedef struct {

@@ -74,6 +74,9 @@ enum {
 #define FXR_PRE_DELAY    (2*FXR_M)            /* symbols before first p/n symbol leaves the MF */
 #define FXR_SYM0_HDR     (FXR_PRE_DELAY + FXR_PN_LEN)          /* 78  */
 #define FXR_SYM0_PAY     (FXR_SYM0_HDR + FXR_HDR_SYM)          /* 309 */
+#define FXR_EQ_TAPS      13     /* optional equaliser: 2*k*p+1 taps, p = 3 */
+#define FXR_EQ_DELAY     3      /* its delay in symbols */
+#define FXR_EQ_MU        0.05f
 
 /* ------------------------------------------------------------------ math (fxref_math.c) */
 void     fxr_init(void);                        /* builds all shared tables once (idempotent) */
@@ -103,6 +106,7 @@ const fxr_c32 *fxr_template(void);              /* 156 */
 const fxr_c32 *fxr_template_fft(void);          /* 512 */
 float          fxr_template_energy(void);       /* sum |s|^2, seq order */
 const fxr_c32 *fxr_pilots(void);                /* 15 */
+void           fxr_eq_init_taps(float *h /* FXR_EQ_TAPS */);    /* equaliser start: Kaiser low-pass, fc = 0.4, As = 40 dB, x 2 fc */
 
 /* ------------------------------------------------------------------ FEC (fxref_fec.c) */
 unsigned fxr_crc_len(int check);
@@ -169,6 +173,9 @@ void      fxr_sync_reset(fxr_sync *q);
 void      fxr_sync_execute(fxr_sync *q, const fxr_c32 *x, unsigned n);
 void      fxr_sync_execute_chunked(fxr_sync *q, const fxr_c32 *x, uint64_t n, unsigned chunk);   /* n samples in calls of `chunk` */
 void      fxr_sync_set_threshold(fxr_sync *q, float t);
+/* optional equaliser stage (liquid: FLEXFRAMESYNC_ENABLE_EQ, compiled out by default): 13-tap eqlms at 2 samples/symbol
+ * behind the matched filter, trained on the 64 p/n symbols, frozen afterwards; every symbol instant moves 3 symbols later */
+void      fxr_sync_set_equalizer(fxr_sync *q, int on);
 /* introspection used by parity tests: estimates of the most recent frame */
 typedef struct {
     uint64_t start;     /* absolute index (since create/reset_counters) of aligned sample 0 */

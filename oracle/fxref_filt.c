@@ -88,6 +88,17 @@ void fxr_firdes_arkaiser(unsigned k, unsigned m, float beta_f, float dt, float *
     for (unsigned i = 0; i < n; i++) h[i] = (float)(hd[i] * g);
 }
 
+/* initial taps of the optional equaliser [RECALLED eqlms_cccf_create_lowpass(2*k*p+1 = 13, fc = 0.4): a Kaiser-windowed
+ * sinc (As = 40 dB) scaled by 2 fc] */
+void fxr_eq_init_taps(float *h)
+{
+    const unsigned n = FXR_EQ_TAPS; const double fc = 0.4, kb = kaiser_beta_As(40.0);
+    for (unsigned i = 0; i < n; i++) {
+        double t = (double)i - (double)(n - 1) / 2.0;
+        h[i] = (float)(sinc(2.0 * fc * t) * kaiser_w(i, n, kb, 0.0) * 2.0 * fc);
+    }
+}
+
 /* ---------------------------------------------------------------- constant tables */
 static float   g_proto[2 * FXR_NPFB * FXR_K * FXR_M + 1];
 static float   g_tx[2 * FXR_K * FXR_M + 1];

@@ -19,7 +19,11 @@
  *  - Half-window energies are balanced-tree sums of the 256 samples of that half.
  *  - After an ALIGN the detector returns to SEEK keeping the second half of the aligned window
  *    as its overlap half (liquid's exact post-detection bookkeeping is not recalled).
- *  - The equaliser (eqlms_cccf) is compiled out, as liquid's FLEXFRAMESYNC_ENABLE_EQ 0 default.
+ *  - The equaliser (eqlms_cccf) is an option, off by default as liquid's FLEXFRAMESYNC_ENABLE_EQ 0 is (fxr_sync_set_equalizer):
+ *    13 taps at 2 samples/symbol behind the matched filter (which is then evaluated at both sample phases), started as a
+ *    Kaiser low-pass, trained by normalised LMS (mu = 0.05) on the 64 p/n symbols, frozen for header and payload; all symbol
+ *    instants move FXR_EQ_DELAY = 3 symbols later [RECALLED flexframesync.c: delay = 2*m + 3].  Sums over the 13 taps run
+ *    in balanced-tree order over 16 slots (what 16 lanes of a wavefront do).
  */
 #include "fxref.h"
 #include <stdlib.h>
@@ -288,6 +292,8 @@ struct fxr_sync {
     float pll_c, pll_s;         /* carrier phasor exp(j pll_th), re-read from the table every 8th symbol, turned incrementally in between */
     fxr_c32 *pay_sym; uint8_t *pay_hard; uint8_t *pay_dec; unsigned pay_cap;
     unsigned pay_counter;
+    /* optional equaliser */
+    int eq_on; fxr_c32 eq_w[FXR_EQ_TAPS], eq_buf[FXR_EQ_TAPS];   /* eq_buf[12] is the newest matched-filter output */
 };
 
 fxr_sync *fxr_sync_create(fxr_callback cb, void *ud)
@@ -305,6 +311,7 @@ void fxr_sync_destroy(fxr_sync *q)
     fxr_qdet_destroy(q->det); free(q->pay_sym); free(q->pay_hard); free(q->pay_dec); free(q);
 }
 void fxr_sync_set_threshold(fxr_sync *q, float t) { fxr_qdet_set_threshold(q->det, t); }
+void fxr_sync_set_equalizer(fxr_sync *q, int on) { q->eq_on = on != 0; }
 void fxr_sync_reset(fxr_sync *q)
 {
     fxr_qdet_reset(q->det);
@@ -314,6 +321,28 @@ void fxr_sync_reset(fxr_sync *q)
 void fxr_sync_last_frame(const fxr_sync *q, fxr_frameinfo *fi) { *fi = q->fi; }
 
 static void sync_run(fxr_sync *q, const fxr_c32 *x, unsigned n, int top);
+
+/* equaliser output: sum_i conj(w[i]) buf[i], balanced tree over 16 slots */
+static fxr_c32 eq_output(const fxr_sync *q)
+{
+    fxr_c32 p[16];
+    for (int i = 0; i < 16; i++) { if (i < FXR_EQ_TAPS) p[i] = cmulc(q->eq_buf[i], q->eq_w[i]); else { p[i].re = 0; p[i].im = 0; } }
+    return fxr_csum_tree(p, 16);
+}
+/* one normalised-LMS step towards the known symbol d, given the output y just produced */
+static void eq_train(fxr_sync *q, fxr_c32 d, fxr_c32 y)
+{
+    float e2[16];
+    for (int i = 0; i < 16; i++) e2[i] = i < FXR_EQ_TAPS ? cm2(q->eq_buf[i]) : 0.0f;
+    float x2 = fxr_sum_tree(e2, 16);
+    if (!(x2 > 0.0f)) return;
+    fxr_c32 e = { d.re - y.re, d.im - y.im };
+    float g = FXR_EQ_MU / x2;
+    for (int i = 0; i < FXR_EQ_TAPS; i++) {
+        fxr_c32 c = cmulc(q->eq_buf[i], e);                   /* buf conj(e) */
+        q->eq_w[i].re = fmaf(g, c.re, q->eq_w[i].re); q->eq_w[i].im = fmaf(g, c.im, q->eq_w[i].im);
+    }
+}
 
 /* mix down, push into the polyphase MF, emit a symbol every second sample */
 static int sync_step(fxr_sync *q, fxr_c32 x, fxr_c32 *y)
@@ -329,9 +358,14 @@ static int sync_step(fxr_sync *q, fxr_c32 x, fxr_c32 *y)
         float h = H[q->pfb + FXR_NPFB * t];
         ar = fmaf(h, w.re, ar); ai = fmaf(h, w.im, ai);
     }
+    if (q->eq_on) {                                             /* every matched-filter output goes through the equaliser's window */
+        memmove(q->eq_buf, q->eq_buf + 1, (FXR_EQ_TAPS - 1) * sizeof(fxr_c32));
+        q->eq_buf[FXR_EQ_TAPS - 1].re = ar * q->mf_scale; q->eq_buf[FXR_EQ_TAPS - 1].im = ai * q->mf_scale;
+    }
     q->mf_counter++;
     if (q->mf_counter < 1) return 0;
     q->mf_counter -= FXR_K;
+    if (q->eq_on) { *y = eq_output(q); return 1; }
     y->re = ar * q->mf_scale; y->im = ai * q->mf_scale;
     return 1;
 }
@@ -443,10 +477,14 @@ static void sync_decode_header(fxr_sync *q)
 static void sync_on_symbol(fxr_sync *q, fxr_c32 y)
 {
     unsigned c = q->sym_counter++;
-    if (c < FXR_SYM0_HDR) return;                       /* MF delay + p/n symbols (no equaliser) */
-    if (c < FXR_SYM0_PAY) {
-        q->hdr_sym[c - FXR_SYM0_HDR] = y;
-        if (c == FXR_SYM0_PAY - 1) sync_decode_header(q);
+    const unsigned dly = q->eq_on ? FXR_EQ_DELAY : 0u;  /* the equaliser delays every symbol instant by 3 */
+    if (c < FXR_SYM0_HDR + dly) {                       /* MF (+ equaliser) delay, then the p/n symbols: they train the equaliser */
+        if (q->eq_on && c >= FXR_PRE_DELAY + dly) eq_train(q, fxr_preamble_pn()[c - FXR_PRE_DELAY - dly], y);
+        return;
+    }
+    if (c < FXR_SYM0_PAY + dly) {
+        q->hdr_sym[c - FXR_SYM0_HDR - dly] = y;
+        if (c == FXR_SYM0_PAY + dly - 1) sync_decode_header(q);
         return;
     }
     /* payload: decision-directed 2nd-order PLL, alpha = 1e-4, beta = sqrt(alpha) [RECALLED nco_crcf_pll_step: frequency +=
@@ -490,6 +528,11 @@ static void sync_run(fxr_sync *q, const fxr_c32 *x, unsigned n, int top)
             q->mix_dl = fxr_rad2u32(q->fi.dphi); q->mix_th = fxr_rad2u32(q->fi.phi);
             q->state = FS_PREAMBLE; q->sym_counter = 0;
             memset(q->win, 0, sizeof q->win); q->wpos = 0;
+            if (q->eq_on) {
+                float h[FXR_EQ_TAPS]; fxr_eq_init_taps(h);
+                for (int t = 0; t < FXR_EQ_TAPS; t++) { q->eq_w[t].re = h[t]; q->eq_w[t].im = 0.0f; }
+                memset(q->eq_buf, 0, sizeof q->eq_buf);
+            }
             fxr_c32 held[FXR_NFFT]; memcpy(held, v, sizeof held);
             sync_run(q, held, FXR_NFFT, 0);             /* re-feed the aligned window */
             continue;

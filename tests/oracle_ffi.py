@@ -105,6 +105,8 @@ def lib():
         L.fxr_sync_destroy.argtypes = [C.c_void_p]
         L.fxr_sync_reset.argtypes = [C.c_void_p]
         L.fxr_sync_set_threshold.argtypes = [C.c_void_p, C.c_float]
+        L.fxr_sync_set_equalizer.argtypes = [C.c_void_p, C.c_int]
+        L.fxr_eq_init_taps.argtypes = [C.c_void_p]
         L.fxr_sync_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         L.fxr_sync_execute_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint]
         L.fxr_sync_last_frame.argtypes = [C.c_void_p, C.POINTER(FrameInfo)]
@@ -151,13 +153,15 @@ class Frame:
 class Sync:
     """Oracle flexframesync driven like the reference block (256-sample execute calls)."""
 
-    def __init__(self, threshold=None):
+    def __init__(self, threshold=None, equalizer=False):
         self.L = lib()
         self.frames = []
         self._cb = CALLBACK(self._on_frame)
         self.q = self.L.fxr_sync_create(self._cb, None)
         if threshold is not None:
             self.L.fxr_sync_set_threshold(self.q, threshold)
+        if equalizer:
+            self.L.fxr_sync_set_equalizer(self.q, 1)
 
     def _on_frame(self, header, hv, payload, plen, pv, st, ud):
         f = Frame()

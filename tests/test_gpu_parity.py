@@ -642,3 +642,51 @@ def test_pipeline_soak_every_block_checked(fx, mode, depth):
         ctx.submit_raw(ptrs, counts, True); inflight += 1
     while inflight: collect(); inflight -= 1
     assert len(got) == 120
+
+
+@pytest.mark.gpu
+def test_equalizer_stage_on_a_multipath_channel(fx, oracle):
+    """The optional equaliser stage (liquid's FLEXFRAMESYNC_ENABLE_EQ, which a stock libliquid compiles out --
+    hence off by default): 13-tap eqlms at 2 samples/symbol behind the matched filter, trained on the 64 p/n symbols,
+    frozen afterwards, symbol instants 3 symbols later.  Three-ray channel, HIP path against the oracle with the stage on
+    (usual tolerances), several segmentations and continuing blocks; and the stage must do its job (EVM improves)."""
+    h = np.zeros(8, np.complex64); h[0] = 1.0; h[3] = 0.35 * np.exp(1j * 1.1); h[5] = 0.2 * np.exp(-1j * 0.4)
+    xs = []
+    for i, (mod, f0, pl) in enumerate([(2, 11, 300), (27, 15, 200), (3, 1, 64)]):
+        x, _ = fx.synth_stream(260_000, stream_id=500 + i, mod=mod, fec0=f0, payload_len=pl, snr_db=27.0, gap=100 + 77 * i)
+        xs.append(np.convolve(x, h)[:len(x)].astype(np.complex64))
+    for s, x in enumerate(xs):
+        of_on = oracle_frames(oracle, x, equalizer=True)
+        of_off = oracle_frames(oracle, x)
+        assert len(of_on) >= 10 and sum(f.payload_valid for f in of_on) >= sum(f.payload_valid for f in of_off)
+        assert np.mean([f.evm for f in of_on if f.header_valid]) < np.mean([f.evm for f in of_off if f.header_valid]) - 1.0    # dB
+        for seg in (0, 8192):
+            ctx = fx.RxContext(1, want_framesyms=True, segment_len=seg, equalizer=True)
+            dev = compare_frames(of_on, ctx.process([x]))
+            ctx.close()
+        # default: stage off, the same samples give what the synchroniser without equaliser gives
+        ctx = fx.RxContext(1, want_framesyms=True)
+        compare_frames(of_off, ctx.process([x])); ctx.close()
+    # continuing blocks, several in flight, all three streams in one context
+    ctx = fx.RxContext(3, want_framesyms=True, equalizer=True); ctx.set_depth(3)
+    cuts = [0, 70_000, 140_123, 200_000, 260_000]
+    got, inflight, keep = [], 0, []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        parts = [np.ascontiguousarray(x[a:b]) for x in xs]; keep.append(parts)
+        if inflight == 3: got += ctx.results(ctx.collect_raw()); inflight -= 1
+        ctx.submit_raw([p.ctypes.data for p in parts], [len(p) for p in parts], False); inflight += 1
+    while inflight: got += ctx.results(ctx.collect_raw()); inflight -= 1
+    for s, x in enumerate(xs):
+        compare_frames(oracle_frames(oracle, x, equalizer=True), [g for g in got if g["stream"] == s])
+    ctx.close()
+    # the drop-in handle: fxrx_sync_set_equalizer
+    L = fx.lib(); frames = []
+    cbf = fx._ffi.FRAMESYNC_CALLBACK(lambda hd, hv, pl, n, pv, st, ud: frames.append((hv, pv, C.string_at(pl, n) if n else b"")) or 0)
+    q = L.flexframesync_create(cbf, None)
+    L.fxrx_sync_set_equalizer(q, 1); L.fxrx_sync_set_block(q, 1 << 18)
+    x = np.concatenate([xs[0], np.zeros((-len(xs[0])) % 256, np.complex64)])
+    L.flexframesync_execute(q, x.ctypes.data, len(x)); L.fxrx_sync_flush(q)
+    while L.fxrx_sync_pending(q): L.flexframesync_execute(q, None, 0)
+    L.flexframesync_destroy(q)
+    of_on = oracle_frames(oracle, xs[0], equalizer=True)
+    assert [(f.header_valid, f.payload_valid, f.payload) for f in of_on] == frames[:len(of_on)] and len(frames) >= len(of_on)
