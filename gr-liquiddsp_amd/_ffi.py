@@ -38,7 +38,7 @@ class TxFrame(C.Structure):                 # fxtx_frame
 
 class Config(C.Structure):                  # fxrx_config
     _fields_ = [("device", C.c_int), ("mode", C.c_int), ("n_streams", C.c_uint), ("threshold", C.c_float),
-                ("segment_len", C.c_uint), ("want_framesyms", C.c_int), ("equalizer", C.c_int)]
+                ("segment_len", C.c_uint), ("want_framesyms", C.c_int), ("equalizer", C.c_int), ("soft_decision", C.c_int)]
 
 
 class Frame(C.Structure):                   # fxrx_frame
@@ -51,7 +51,8 @@ class Frame(C.Structure):                   # fxrx_frame
                 ("payload", C.POINTER(C.c_ubyte)), ("payload_len", C.c_uint),
                 ("framesyms", C.POINTER(FxComplex)), ("num_framesyms", C.c_uint),
                 ("evm_db", C.c_float), ("rssi_db", C.c_float), ("cfo", C.c_float), ("evm_sum", C.c_float),
-                ("mod_scheme", C.c_uint), ("mod_bps", C.c_uint), ("check", C.c_uint), ("fec0", C.c_uint), ("fec1", C.c_uint)]
+                ("mod_scheme", C.c_uint), ("mod_bps", C.c_uint), ("check", C.c_uint), ("fec0", C.c_uint), ("fec1", C.c_uint),
+                ("soft_bits", C.POINTER(C.c_ubyte)), ("num_soft_bits", C.c_uint)]
 
 
 class Timing(C.Structure):                  # fxrx_timing
@@ -67,7 +68,7 @@ class Timing(C.Structure):                  # fxrx_timing
 # every symbol include/fxrx.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
     "flexframesync_create", "flexframesync_destroy", "flexframesync_execute", "flexframesync_reset",
-    "fxrx_sync_flush", "fxrx_sync_set_block", "fxrx_sync_set_threshold", "fxrx_sync_set_equalizer", "fxrx_sync_pending", "fxrx_sync_errors", "fxrx_qdet_errors",
+    "fxrx_sync_flush", "fxrx_sync_set_block", "fxrx_sync_set_threshold", "fxrx_sync_set_equalizer", "fxrx_sync_set_soft", "fxrx_sync_pending", "fxrx_sync_errors", "fxrx_qdet_errors",
     "msequence_create", "msequence_advance", "msequence_destroy",
     "qdetector_cccf_create_linear", "qdetector_cccf_destroy", "qdetector_cccf_set_threshold",
     "qdetector_cccf_execute", "qdetector_cccf_get_tau", "qdetector_cccf_get_gamma", "qdetector_cccf_get_dphi",
@@ -146,6 +147,7 @@ def lib():
     L.fxrx_sync_set_block.argtypes = [C.c_void_p, C.c_uint]; L.fxrx_sync_set_block.restype = None
     L.fxrx_sync_set_threshold.argtypes = [C.c_void_p, C.c_float]; L.fxrx_sync_set_threshold.restype = None
     L.fxrx_sync_set_equalizer.argtypes = [C.c_void_p, C.c_int]; L.fxrx_sync_set_equalizer.restype = None
+    L.fxrx_sync_set_soft.argtypes = [C.c_void_p, C.c_int]; L.fxrx_sync_set_soft.restype = None
     L.fxrx_sync_pending.argtypes = [C.c_void_p]; L.fxrx_sync_pending.restype = C.c_uint
     L.fxrx_sync_errors.argtypes = [C.c_void_p]; L.fxrx_sync_errors.restype = C.c_uint
     L.fxrx_qdet_errors.argtypes = [C.c_void_p]; L.fxrx_qdet_errors.restype = C.c_uint

@@ -207,7 +207,7 @@ struct FxOutRec {
     uint32_t payload_valid;              // fx_paydec_kernel
     uint32_t status;
     uint8_t  header[FX_HDR_DEC];
-    uint32_t pad_[1];
+    uint32_t byte_off;                   // the frame's offset in the byte arenas (soft values: 8 x this)
 };
 
 // ---- frame generator (fx_txgen_kernel) ----

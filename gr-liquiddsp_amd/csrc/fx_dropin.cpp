@@ -23,7 +23,7 @@ struct HeldFrame {
 // ------------------------------------------------------------------------------------------ flexframesync
 struct fxrx_sync_s {
     framesync_callback cb = nullptr; void *ud = nullptr;
-    fxrx_ctx *ctx = nullptr; float threshold = 0.0f; int equalizer = 0;
+    fxrx_ctx *ctx = nullptr; float threshold = 0.0f; int equalizer = 0, soft = 0;
     std::vector<fx_complex> queue; unsigned block = 1u << 16;
     std::deque<HeldFrame> pending; HeldFrame current;
 
@@ -98,7 +98,7 @@ unsigned int fxrx_sync_errors(flexframesync q) { return q ? q->errors : 0; }
 static void sync_recreate(flexframesync q, const char *what)
 {
     fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1;
-    cfg.threshold = q->threshold; cfg.equalizer = q->equalizer;
+    cfg.threshold = q->threshold; cfg.equalizer = q->equalizer; cfg.soft_decision = q->soft;
     if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
     fxrx_ctx *nc = fxrx_create(&cfg);
     if (!nc) { q->errors++; std::fprintf(stderr, "libfxrx: %s: %s (setting unchanged)\n", what, fxrx_last_error()); return; }
@@ -107,6 +107,7 @@ static void sync_recreate(flexframesync q, const char *what)
 }
 void fxrx_sync_set_threshold(flexframesync q, float t) { if (!q) return; q->threshold = t; sync_recreate(q, "fxrx_sync_set_threshold"); }
 void fxrx_sync_set_equalizer(flexframesync q, int on) { if (!q) return; q->equalizer = on ? 1 : 0; sync_recreate(q, "fxrx_sync_set_equalizer"); }
+void fxrx_sync_set_soft(flexframesync q, int on) { if (!q) return; q->soft = on ? 1 : 0; sync_recreate(q, "fxrx_sync_set_soft"); }
 
 }  // extern "C"
 

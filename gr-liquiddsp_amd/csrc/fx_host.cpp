@@ -55,9 +55,11 @@ extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, con
                                       const FxFrame *chain, float2 *sym_raw, const FxTables *T);
 extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs, const FxTables *T);
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx,
-                                       const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out,
-                                       FxOutRec *recs, FxPayResult *res, const FxTables *T);
+extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
+                                       const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, uint8_t *soft_arena,
+                                       unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T);
+extern "C" hipError_t fx_launch_softdemod(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
+                                          const float2 *framesyms, const uint8_t *hard, uint8_t *soft_arena, const FxTables *T);
 
 namespace {
 
@@ -141,9 +143,9 @@ struct Slot {
     uint32_t run_cap = 0, chain_cap = 0, mf_cap = 0, frame_slots = 0;
     uint64_t sym_cap = 0, byte_cap = 0, dw_cap = 0, out_cap = 0;
     // payload arenas
-    DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB; DevBuf<unsigned long long> d_dw;
+    DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_soft; DevBuf<unsigned long long> d_dw;
     // results (pinned host memory the kernels write into)
-    PinBuf<FxBlockHdr> h_hdr; PinBuf<FxOutRec> h_recs; PinBuf<uint8_t> h_out; PinBuf<float2> h_framesyms;
+    PinBuf<FxBlockHdr> h_hdr; PinBuf<FxOutRec> h_recs; PinBuf<uint8_t> h_out, h_soft; PinBuf<float2> h_framesyms;
     std::vector<Out> out;
     uint64_t n_syms = 0;
     fxrx_timing timing{};
@@ -431,6 +433,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_framesyms.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
                     sl.d_bufA.reserve(sl.byte_cap) || sl.d_bufB.reserve(sl.byte_cap) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.want_framesyms && sl.h_framesyms.reserve(sl.sym_cap)) return FXRX_ERR_HIP;
+    if (!detect && c->cfg.soft_decision && (sl.d_soft.reserve(8 * sl.byte_cap) || (c->cfg.want_framesyms && sl.h_soft.reserve(8 * sl.byte_cap)))) return FXRX_ERR_HIP;
 #ifdef FX_STAMPS
     if (!detect && sl.d_pres.reserve(chain_slots)) return FXRX_ERR_HIP;
 #endif
@@ -503,15 +506,22 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
         // decode: one wave per frame.  The lean instance has no loop (it would double its registers): its grid covers what
         // the last block held plus a margin, and a second, usually empty launch covers the rest of the list's capacity in
         // big workgroups (few of them).  The Reed-Solomon instance strides.
+        const int soft = c->cfg.soft_decision ? 1 : 0;
+        if (soft) {
+            // per-bit soft values from the carrier-recovered symbols (data parallel, off the PLL's recurrence); the decoder
+            // de-interleaves them in place, so a caller that wants to see them gets a copy first
+            HIP_OK(fx_launch_softdemod(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_framesyms.p, sl.d_hard.p, sl.d_soft.p, c->d_tables));
+            if (c->cfg.want_framesyms) HIP_OK(hipMemcpyAsync(sl.h_soft.p, sl.d_soft.p, 8 * sl.byte_cap, hipMemcpyDeviceToHost, st));
+        }
         const unsigned dec_first = (unsigned)std::min<uint64_t>(chain_slots, fh);
-        HIP_OK(fx_launch_paydec(0, 0, dec_first, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p,
-                                sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+        HIP_OK(fx_launch_paydec(0, soft, 0, dec_first, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p,
+                                sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
         if (dec_first < chain_slots)
-            HIP_OK(fx_launch_paydec(0, dec_first, chain_slots - dec_first, 8u, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
-                                    sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+            HIP_OK(fx_launch_paydec(0, soft, dec_first, chain_slots - dec_first, 8u, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
+                                    sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
         const unsigned rs_grid = (unsigned)std::min<uint64_t>(chain_slots, std::max<uint64_t>(64, c->rs_hint + c->rs_hint / 2));
-        HIP_OK(fx_launch_paydec(1, 0, rs_grid, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
-                                sl.d_bufB.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+        HIP_OK(fx_launch_paydec(1, soft, 0, rs_grid, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
+                                sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[7], st));
         // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
         if (c->cfg.want_framesyms)
@@ -659,6 +669,10 @@ int fxrx_collect(fxrx_ctx *c)
             f.payload = sl.h_out.p + r.out_off; f.payload_valid = (int)r.payload_valid;
             f.evm_sum = r.evm_sum; f.evm_db = 10.0f * log10f(r.evm_sum / (float)(r.nsym ? r.nsym : 1));
             f.framesyms = c->cfg.want_framesyms ? (const fx_complex *)(sl.h_framesyms.p + r.sym_off) : nullptr;
+            if (c->cfg.soft_decision && c->cfg.want_framesyms) {
+                f.soft_bits = sl.h_soft.p + 8 * (size_t)r.byte_off;
+                f.num_soft_bits = 8u * fx::packet_plan(r.pay_len, r.check, r.fec0, r.fec1).l1;
+            }
         }
     }
     sl.n_syms = h.sym_total;

@@ -1332,7 +1332,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             const uint32_t *hw = reinterpret_cast<const uint32_t *>(fp->header); uint32_t *rw = reinterpret_cast<uint32_t *>(u.r.header);
 #pragma unroll
             for (int i = 0; i < FX_HDR_DEC / 4; i++) rw[i] = hw[i];
-            u.r.pad_[0] = 0;
+            u.r.byte_off = byte_off;
             uint4 *dst = reinterpret_cast<uint4 *>(recs + g);
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(FxOutRec) / 16); i++) dst[i] = u.q[i];
@@ -1667,6 +1667,50 @@ __device__ __forceinline__ void deinterleave_wave(uint8_t *x, uint32_t n, int la
     }
 }
 
+// the same swaps on an array of soft values, eight bytes per packet byte (MSB first): a masked swap of two 64-bit words
+__device__ __forceinline__ void deinterleave_soft_wave(uint8_t *xs, uint32_t n, int lane)
+{
+    if (n < 2) return;
+    unsigned long long *x = reinterpret_cast<unsigned long long *>(xs);
+    const uint32_t M = 1u + (uint32_t)floorf(sqrtf((float)n));
+    uint32_t N = n / M; while (n >= M * N) N++;
+    const uint32_t n2 = n / 2, nn0 = n / 3, step_q = 64u / M, step_m = 64u % M;
+    for (int p = 3; p >= 0; p--) {
+        const uint32_t Np = N + (p == 0 ? 0u : (p == 1 ? 2u : (p == 2 ? 4u : 8u)));
+        // bit mask ff / 0f / 55 / 33 -> the bytes (soft values) of the word that change places
+        const unsigned long long mk = p == 0 ? 0xFFFFFFFFFFFFFFFFull : (p == 1 ? 0xFFFFFFFF00000000ull : (p == 2 ? 0xFF00FF00FF00FF00ull : 0xFFFF0000FFFF0000ull));
+        uint32_t m = (uint32_t)lane % M, q = (uint32_t)lane / M, i_base = 0;
+        const uint32_t max_iter = (M * (Np + 1u)) / 64u + 2u;
+        for (uint32_t it = 0; i_base < n2 && it < max_iter; it++) {
+            const uint32_t nn = q == 0 ? nn0 : (nn0 + q) % Np;
+            const uint32_t j = m * Np + nn;
+            const bool valid = j < n2;
+            const unsigned long long mask = __ballot(valid);
+            const uint32_t i = i_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+            if (valid && i < n2) {
+                const uint32_t a = 2u * i, b = 2u * j + 1u;
+                const unsigned long long va = x[a], vb = x[b];
+                x[a] = (va & ~mk) | (vb & mk); x[b] = (va & mk) | (vb & ~mk);
+            }
+            i_base += (uint32_t)__popcll(mask);
+            m += step_m; q += step_q;
+            if (m >= M) { m -= M; q++; }
+        }
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    }
+}
+// hard decisions of n packet bytes from their soft values (value > 127 = 1)
+__device__ __forceinline__ void soft_to_hard_wave(const uint8_t *soft, uint8_t *out, uint32_t n, int lane)
+{
+    for (uint32_t j = lane; j < n; j += DEC_THREADS) {
+        const unsigned long long w = *reinterpret_cast<const unsigned long long *>(soft + 8 * (size_t)j);
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) v = (v << 1) | ((((unsigned)(w >> (8 * b)) & 255u) > 127u) ? 1u : 0u);
+        out[j] = (uint8_t)v;
+    }
+}
+
 // SECDED with nd data bytes per block behind one parity byte (nd = 2, 4, 8), Hsiao columns `col`
 __device__ __forceinline__ void secded_decode(const uint8_t *col, uint32_t nd, uint32_t n, const uint8_t *enc, uint8_t *dec, int lane)
 {
@@ -1826,12 +1870,23 @@ __device__ __forceinline__ uint32_t acs_exchange_min(uint32_t A, uint32_t B)
     else return min(A, (uint32_t)__builtin_amdgcn_mov_dpp((int)B, 0xB1, 0xf, 0xf, false));
 }
 
-template <int PH, bool PUNCT>
+// VM: 0 hard decisions, rate 1/2 (table-driven increments); 1 hard decisions, punctured; 2 soft decisions (any puncturing)
+template <int PH, int VM>
 __device__ __forceinline__ void acs_step(uint32_t &P, unsigned cu, const unsigned (&ta)[6], const unsigned (&tb)[6], int lane, unsigned &hist)
 {
-    // cu: this step's received code word, already in a scalar register -- PUNCT: R4 | H4<<4 | (2*nbits)<<8, else 8*r
+    // cu: this step's received code word, already in a scalar register -- VM 1: R4 | H4<<4 | (2*nbits)<<8; VM 0: 8*r;
+    // VM 2: soft value A | soft value B << 8 | (present ? 255 : 0) << 16 | likewise B << 24
     uint32_t A, B;
-    if constexpr (PUNCT) {
+    if constexpr (VM == 2) {
+        // cost of an expected bit e against a soft value v: e ? 255 - v : v = v ^ (e ? 255 : 0); ta[PH] holds the lane's two
+        // expected bits as byte masks (role-adjusted), one v_sad_u8 adds the two byte costs
+        const unsigned hi = ((unsigned)lane >> (5 - PH)) & 1u;
+        const unsigned t = ((cu & 0xffffu) ^ ta[PH]) & (cu >> 16);
+        const unsigned a = 2u * __builtin_amdgcn_sad_u8(t, 0u, 0u) + hi;
+        const unsigned b = 2u * (((cu >> 16) & 255u) + (cu >> 24)) - a;               // 2 * 255 * bits present - a
+        A = P + a;
+        B = P + b + tb[PH];
+    } else if constexpr (VM == 1) {
         const unsigned hi = ((unsigned)lane >> (5 - PH)) & 1u;
         const unsigned t = (ta[PH] ^ (cu & 15u)) & ((cu >> 4) & 15u);
         const unsigned a = __popc(t) + hi;                                             // 2 * bm (role-adjusted) + hi
@@ -1847,7 +1902,8 @@ __device__ __forceinline__ void acs_step(uint32_t &P, unsigned cu, const unsigne
     P = m & ~1u;
 }
 
-template <bool PUNCT>
+// enc: VM 0 / 1: the coded bits, packed; VM 2: one soft byte per coded bit
+template <int VM>
 __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc, uint8_t *dec, unsigned long long *dw, uint8_t *scratch, int lane, uint32_t *stamp_fwd)
 {
 #ifdef FX_STAMPS
@@ -1864,7 +1920,8 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
         const unsigned sr = ((st << 1) | hi) & 0x7f;                                          // own branch: (st) -> rotl(st,1)
         unsigned e = ((__popc(sr & 0x6d) & 1) ? 3u : 0u) | ((__popc(sr & 0x4f) & 1) ? 12u : 0u);
         if (ph < 2 && hi) e ^= 15u;                                                           // swapped roles: A = cross key
-        if (PUNCT) { ta[ph] = e; tb[ph] = 2u * hi; }
+        if (VM == 2) { ta[ph] = ((e & 3u) ? 0xffu : 0u) | ((e & 12u) ? 0xff00u : 0u); tb[ph] = 2u * hi; }
+        else if (VM == 1) { ta[ph] = e; tb[ph] = 2u * hi; }
         else {
             unsigned wa = 0, wb = 0;
 #pragma unroll
@@ -1893,9 +1950,14 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
         const unsigned hasA = (pa >> col) & 1, hasB = (pb >> col) & 1;
         uint32_t nb = (p == 1) ? 2 * t : t + (t + (unsigned)p - 1) / (unsigned)p;       // coded bits before step t
         unsigned ra = 0, rb = 0;
+        if (VM == 2) {
+            if (hasA) { ra = enc[nb]; nb++; }
+            if (hasB) { rb = enc[nb]; }
+            return ra | (rb << 8) | (hasA * 0xff0000u) | (hasB * 0xff000000u);
+        }
         if (hasA) { ra = getbit(enc, nb); nb++; }
         if (hasB) { rb = getbit(enc, nb); }
-        if (!PUNCT) return 8u * (ra | (rb << 1));
+        if (VM == 0) return 8u * (ra | (rb << 1));
         return (ra * 3u) | (rb * 12u) | ((hasA * 3u | hasB * 12u) << 4) | ((2u * (hasA + hasB)) << 8);
     };
     uint32_t P = (lane == 0) ? 0u : (1u << 25);            // state 0 sits in lane 0 at every phase
@@ -1917,17 +1979,17 @@ __device__ __forceinline__ void viterbi27(int p, uint32_t n, const uint8_t *enc,
                 case 0:
                     if (u + 6 <= ue) {
                         const unsigned c0 = cw(u), c1 = cw(u + 1), c2 = cw(u + 2), c3 = cw(u + 3), c4 = cw(u + 4), c5 = cw(u + 5);
-                        acs_step<0, PUNCT>(P, c0, ta, tb, lane, hist[h]); acs_step<1, PUNCT>(P, c1, ta, tb, lane, hist[h]);
-                        acs_step<2, PUNCT>(P, c2, ta, tb, lane, hist[h]); acs_step<3, PUNCT>(P, c3, ta, tb, lane, hist[h]);
-                        acs_step<4, PUNCT>(P, c4, ta, tb, lane, hist[h]); acs_step<5, PUNCT>(P, c5, ta, tb, lane, hist[h]);
+                        acs_step<0, VM>(P, c0, ta, tb, lane, hist[h]); acs_step<1, VM>(P, c1, ta, tb, lane, hist[h]);
+                        acs_step<2, VM>(P, c2, ta, tb, lane, hist[h]); acs_step<3, VM>(P, c3, ta, tb, lane, hist[h]);
+                        acs_step<4, VM>(P, c4, ta, tb, lane, hist[h]); acs_step<5, VM>(P, c5, ta, tb, lane, hist[h]);
                         u += 6;
-                    } else { acs_step<0, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; }
+                    } else { acs_step<0, VM>(P, cw(u), ta, tb, lane, hist[h]); u++; }
                     break;
-                case 1: acs_step<1, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
-                case 2: acs_step<2, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
-                case 3: acs_step<3, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
-                case 4: acs_step<4, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
-                default: acs_step<5, PUNCT>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 1: acs_step<1, VM>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 2: acs_step<2, VM>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 3: acs_step<3, VM>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                case 4: acs_step<4, VM>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
+                default: acs_step<5, VM>(P, cw(u), ta, tb, lane, hist[h]); u++; break;
                 }
             }
         }
@@ -2082,10 +2144,13 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 // workgroups keep a block's decode waves together on few CUs instead of sprinkling one wave over every CU, which
 // matters to the walker of the next block (its workgroups need a whole, empty register file each).
 #define DEC_MAX_WAVES 8
-// one frame, one wave
-template <bool WITH_RS>
+// one frame, one wave.  SOFT: decoding from per-bit soft values (fx_softdemod_kernel wrote them, 8 per packet byte):
+// a convolutional stage decodes from soft values as long as nothing before it took hard decisions -- the stage nearest the
+// channel (fec1), and fec0 too when fec1 is FEC_NONE; every other stage takes hard decisions (value > 127).
+template <bool WITH_RS, bool SOFT>
 __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard, uint8_t *bufA,
-                                          uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+                                          uint8_t *bufB, uint8_t *soft_arena, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res,
+                                          const FxTables *T)
 {
     const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
@@ -2098,6 +2163,41 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
     const uint8_t *hs = hard + job.sym_off;
     const unsigned bps = job.bps;
     FX_STAMP_INIT;
+    uint32_t status = 0;
+    const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
+    if constexpr (SOFT) {
+        uint8_t *S = soft_arena + 8 * (size_t)job.byte_off;
+        deinterleave_soft_wave(S, job.l1, lane);
+        FX_STAMP(1);
+        bool still_soft = false;
+        if (pc1) viterbi27<2>(pc1, job.l0, S, B, dw_arena + job.dw_off, A, lane, nullptr);
+        else if (job.fec1 == FX_FEC_NONE) still_soft = true;
+        else {
+            soft_to_hard_wave(S, A, job.l1, lane);
+            __threadfence_block(); __builtin_amdgcn_wave_barrier();
+            block_fec_decode<WITH_RS>(job.fec1, job.l0, A, B, T, lane);
+        }
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+        FX_STAMP(2);
+        if (still_soft) {
+            deinterleave_soft_wave(S, job.l0, lane);
+            FX_STAMP(3);
+            if (pc0) viterbi27<2>(pc0, job.k, S, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
+            else {
+                soft_to_hard_wave(S, B, job.l0, lane);
+                __threadfence_block(); __builtin_amdgcn_wave_barrier();
+                block_fec_decode<WITH_RS>(job.fec0, job.k, B, A, T, lane);
+            }
+        } else {
+            deinterleave_wave(B, job.l0, lane);
+            FX_STAMP(3);
+            if (pc0 == 1) viterbi27<0>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
+            else if (pc0) viterbi27<1>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
+            else block_fec_decode<WITH_RS>(job.fec0, job.k, B, A, T, lane);
+        }
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+        FX_STAMP(4);
+    } else {
     // 1. hard symbols -> packet bytes (MSB first)
     for (uint32_t j = lane; j < job.l1; j += DEC_THREADS) {
         unsigned v = 0;
@@ -2113,21 +2213,20 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
     // 2. outer plan (fec1): de-interleave l1 bytes in place, decode -> l0 bytes
     deinterleave_wave(A, job.l1, lane);
     FX_STAMP(1);
-    uint32_t status = 0;
-    const int pc1 = conv_p(job.fec1), pc0 = conv_p(job.fec0);
-    if (pc1 == 1) viterbi27<false>(1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
-    else if (pc1) viterbi27<true>(pc1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
+    if (pc1 == 1) viterbi27<0>(1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
+    else if (pc1) viterbi27<1>(pc1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
     else block_fec_decode<WITH_RS>(job.fec1, job.l0, A, B, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(2);
     // 3. inner plan (fec0): de-interleave l0 bytes in place, decode -> k bytes
     deinterleave_wave(B, job.l0, lane);
     FX_STAMP(3);
-    if (pc0 == 1) viterbi27<false>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
-    else if (pc0) viterbi27<true>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
+    if (pc0 == 1) viterbi27<0>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
+    else if (pc0) viterbi27<1>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
     else block_fec_decode<WITH_RS>(job.fec0, job.k, B, A, T, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(4);
+    }
     // 4. de-whiten, CRC, copy out (the payload goes straight into the host's result arena)
     const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
     for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
@@ -2163,10 +2262,10 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
     FX_STAMP(5);
 }
 
-template <bool WITH_RS>
+template <bool WITH_RS, bool SOFT>
 __global__ __launch_bounds__(WITH_RS ? DEC_THREADS : DEC_THREADS * DEC_MAX_WAVES)
 void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, const uint8_t *hard, uint8_t *bufA,
-                      uint8_t *bufB, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+                      uint8_t *bufB, uint8_t *soft_arena, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
 {
     // The list's length is known on the device only.  The lean instance has no loop around its body (a grid-stride loop
     // doubles the register footprint): the host launches it over the list's capacity -- a grid sized from the previous block
@@ -2178,21 +2277,106 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
     if (ji0 >= njobs) return;
     __builtin_amdgcn_s_setprio(2);
     if constexpr (WITH_RS) {
-        for (uint32_t ji = ji0; ji < njobs; ji += gridDim.x * wpg) dec_frame<true>(ji, lane, jobs, job_idx, hard, bufA, bufB, dw_arena, out, recs, res, T);
+        for (uint32_t ji = ji0; ji < njobs; ji += gridDim.x * wpg) dec_frame<true, SOFT>(ji, lane, jobs, job_idx, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T);
     } else {
-        dec_frame<false>(ji0, lane, jobs, job_idx, hard, bufA, bufB, dw_arena, out, recs, res, T);
+        dec_frame<false, SOFT>(ji0, lane, jobs, job_idx, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T);
     }
 }
 
-extern "C" hipError_t fx_launch_paydec(int with_rs, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
-                                       const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena,
-                                       uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
+                                       const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, uint8_t *soft_arena,
+                                       unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
 {
     if (grid_waves == 0) return hipSuccess;
     const unsigned w = with_rs ? 1u : (waves_per_wg < 1u ? 1u : (waves_per_wg > DEC_MAX_WAVES ? DEC_MAX_WAVES : waves_per_wg));
     const dim3 grid((grid_waves + w - 1) / w), block(DEC_THREADS * w);
-    if (with_rs) hipLaunchKernelGGL(fx_paydec_kernel<true>, grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, dw_arena, out, recs, res, T);
-    else hipLaunchKernelGGL(fx_paydec_kernel<false>, grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, dw_arena, out, recs, res, T);
+#define FX_DEC_LAUNCH(RS, SF) hipLaunchKernelGGL((fx_paydec_kernel<RS, SF>), grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T)
+    if (with_rs) { if (soft) FX_DEC_LAUNCH(true, true); else FX_DEC_LAUNCH(true, false); }
+    else { if (soft) FX_DEC_LAUNCH(false, true); else FX_DEC_LAUNCH(false, false); }
+#undef FX_DEC_LAUNCH
+    return hipGetLastError();
+}
+
+// ===================================================================== payload: soft decisions (optional)
+// One thread per payload symbol: the carrier-recovered symbol (fx_paypll_kernel left it in framesyms) -> bps soft values,
+// 0 = surely 0 ... 255 = surely 1, MSB of the symbol first, written at the bit's position in the packet (8 soft values per
+// packet byte).  soft = clamp(rint(127 + 16 gamma (d0 - d1))), gamma = 1.2 M, d0 / d1 = squared distance to the nearest point
+// whose label has a 0 / a 1 at that bit: exhaustive over the M phases for PSK, per axis for ASK / QAM; differential PSK: the
+// hard symbol's bits as 0 / 255.  Work items are the matched filter's (frame, 1024 symbols).
+__device__ __forceinline__ uint8_t soft_byte(float d0, float d1, float gamma16)
+{
+    float t = rintf(fmaf(d0 - d1, gamma16, 127.0f));
+    t = fminf(fmaxf(t, 0.0f), 255.0f);
+    return (uint8_t)t;
+}
+__device__ __forceinline__ void soft_axis(float v, unsigned nb, float al, float gamma16, uint8_t *soft)
+{
+    const unsigned L = 1u << nb;
+    float d0[3] = { 1e30f, 1e30f, 1e30f }, d1[3] = { 1e30f, 1e30f, 1e30f };
+    for (unsigned i = 0; i < L; i++) {
+        const float dx = v - (2.0f * (float)i - (float)(L - 1)) * al, d = dx * dx;
+        const unsigned g = gray_enc(i);
+#pragma unroll
+        for (unsigned b = 0; b < 3; b++) if (b < nb) { if ((g >> (nb - 1 - b)) & 1u) d1[b] = fminf(d1[b], d); else d0[b] = fminf(d0[b], d); }
+    }
+#pragma unroll
+    for (unsigned b = 0; b < 3; b++) if (b < nb) soft[b] = soft_byte(d0[b], d1[b], gamma16);
+}
+
+extern "C" __global__ __launch_bounds__(256)
+void fx_softdemod_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr, const float2 *framesyms,
+                         const uint8_t *hard, uint8_t *soft_arena, const FxTables *T)
+{
+    const uint32_t nitems = hdr->n_mfblk;
+    const float2 *sc = T->sc;
+    for (uint32_t bi = blockIdx.x; bi < nitems; bi += gridDim.x) {
+        const FxPayJob job = jobs[blk_job[bi]];
+        const uint32_t c0 = blk_c0[bi], ns = min(1024u, job.nsym - c0);
+        const unsigned ms = job.ms, bps = job.bps;
+        const float gamma16 = 1.2f * (float)(1u << bps) * 16.0f;
+        uint8_t *S = soft_arena + 8 * (size_t)job.byte_off;
+        const uint32_t nbits = 8u * job.l1;
+        for (uint32_t i = threadIdx.x; i < ns; i += blockDim.x) {
+            const uint32_t c = c0 + i;
+            const float2 r = framesyms[(size_t)job.sym_off + c];
+            uint8_t sb[8];
+            switch (ms) {
+            case FX_MODEM_DPSK2: case FX_MODEM_DPSK4: case FX_MODEM_DPSK8: {
+                const unsigned hsym = hard[(size_t)job.sym_off + c];
+                for (unsigned b = 0; b < bps; b++) sb[b] = ((hsym >> (bps - 1 - b)) & 1u) ? 255 : 0;
+                break; }
+            case FX_MODEM_PSK2: case FX_MODEM_PSK4: case FX_MODEM_PSK8: case FX_MODEM_PSK16: {
+                float d0[4] = { 1e30f, 1e30f, 1e30f, 1e30f }, d1[4] = { 1e30f, 1e30f, 1e30f, 1e30f };
+                for (unsigned k = 0; k < (1u << bps); k++) {
+                    const float2 p = psk_point(k, bps, sc);
+                    const float dx = r.x - p.x, dy = r.y - p.y, d = fmaf(dx, dx, dy * dy);
+                    const unsigned g = gray_enc(k);
+#pragma unroll
+                    for (unsigned b = 0; b < 4; b++) if (b < bps) { if ((g >> (bps - 1 - b)) & 1u) d1[b] = fminf(d1[b], d); else d0[b] = fminf(d0[b], d); }
+                }
+#pragma unroll
+                for (unsigned b = 0; b < 4; b++) if (b < bps) sb[b] = soft_byte(d0[b], d1[b], gamma16);
+                break; }
+            case FX_MODEM_ASK4: soft_axis(r.x, 2, 0.447213595f, gamma16, sb); break;
+            case FX_MODEM_QPSK: soft_axis(-r.y, 1, 0.70710678118654752f, gamma16, sb); soft_axis(-r.x, 1, 0.70710678118654752f, gamma16, sb + 1); break;
+            default: {
+                unsigned mi, mq; float al;
+                if (ms == FX_MODEM_QAM16) { mi = 2; mq = 2; al = 0.316227766f; }
+                else if (ms == FX_MODEM_QAM32) { mi = 3; mq = 2; al = 0.196116135f; }
+                else { mi = 3; mq = 3; al = 0.154303350f; }
+                soft_axis(r.x, mi, al, gamma16, sb); soft_axis(r.y, mq, al, gamma16, sb + mi);
+                break; }
+            }
+            for (unsigned b = 0; b < bps; b++) { const uint32_t q = c * bps + b; if (q < nbits) S[q] = sb[b]; }
+        }
+    }
+}
+
+extern "C" hipError_t fx_launch_softdemod(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
+                                          const float2 *framesyms, const uint8_t *hard, uint8_t *soft_arena, const FxTables *T)
+{
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(fx_softdemod_kernel, dim3(grid), dim3(256), 0, st, jobs, blk_job, blk_c0, hdr, framesyms, hard, soft_arena, T);
     return hipGetLastError();
 }
 

@@ -28,15 +28,16 @@ def _frame_to_dict(f, copy_syms):
         d["framesyms"] = np.frombuffer(buf, dtype=np.complex64).copy()
     else:
         d["framesyms"] = None
+    d["soft_bits"] = np.frombuffer(C.string_at(f.soft_bits, f.num_soft_bits), np.uint8) if (copy_syms and f.soft_bits and f.num_soft_bits) else None
     return d
 
 
 class RxContext:
     """fxrx_ctx wrapper.  Raises RxError when the library or a HIP device is missing (no fallback)."""
 
-    def __init__(self, n_streams=1, mode=MODE_FLEX_RX, device=0, threshold=0.0, segment_len=0, want_framesyms=False, equalizer=False):
+    def __init__(self, n_streams=1, mode=MODE_FLEX_RX, device=0, threshold=0.0, segment_len=0, want_framesyms=False, equalizer=False, soft_decision=False):
         self.L = _ffi.lib()
-        cfg = _ffi.Config(device, mode, n_streams, threshold, segment_len, 1 if want_framesyms else 0, 1 if equalizer else 0)
+        cfg = _ffi.Config(device, mode, n_streams, threshold, segment_len, 1 if want_framesyms else 0, 1 if equalizer else 0, 1 if soft_decision else 0)
         self.h = self.L.fxrx_create(C.byref(cfg))
         if not self.h:
             raise RxError("fxrx_create failed: %s" % self.L.fxrx_last_error().decode())

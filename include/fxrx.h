@@ -74,6 +74,7 @@ void fxrx_sync_flush(flexframesync q);
 void fxrx_sync_set_block(flexframesync q, unsigned int samples);
 void fxrx_sync_set_threshold(flexframesync q, float threshold);
 void fxrx_sync_set_equalizer(flexframesync q, int on);   /* re-creates the context like fxrx_sync_set_threshold */
+void fxrx_sync_set_soft(flexframesync q, int on);        /* likewise: soft-decision payload decoding */
 unsigned int fxrx_sync_pending(flexframesync q);     /* completed frames not yet delivered */
 /* the liquid signatures return void: a block that failed on the GPU keeps its samples queued (they run again with the
  * next call), the text stays in fxrx_last_error(), one line goes to stderr and this counter goes up */
@@ -136,6 +137,9 @@ typedef struct {
     int          equalizer;      /* 1: optional equaliser stage on (liquid: FLEXFRAMESYNC_ENABLE_EQ, compiled out of a stock libliquid):
                                     13-tap eqlms at 2 samples/symbol behind the matched filter, trained on the 64 p/n symbols, frozen
                                     afterwards; symbol instants move 3 symbols later.  0 (default): what flexframesync executes */
+    int          soft_decision;  /* 1: decode the payload from per-bit soft values (liquid: flexframesync_decode_payload_soft, which the
+                                    reference never calls): soft-input Viterbi for the convolutional stage(s) nearest the channel.
+                                    With want_framesyms the soft values themselves come back too (fxrx_frame.soft_bits).  0: hard */
 } fxrx_config;
 
 typedef struct {
@@ -151,6 +155,8 @@ typedef struct {
     const fx_complex *framesyms; unsigned int num_framesyms;   /* host pointer or NULL */
     float        evm_db, rssi_db, cfo, evm_sum;
     unsigned int mod_scheme, mod_bps, check, fec0, fec1;
+    const unsigned char *soft_bits; unsigned int num_soft_bits;   /* soft_decision + want_framesyms: one byte per coded bit in channel
+                                                                     order, 0 = surely 0 ... 255 = surely 1; else NULL */
 } fxrx_frame;
 
 typedef struct fxrx_ctx_s fxrx_ctx;

@@ -119,6 +119,7 @@ void     fxr_fec_decode(int fs, unsigned dec_len, const uint8_t *enc, uint8_t *d
 unsigned fxr_packet_enc_len(unsigned n, int check, int fec0, int fec1);
 void     fxr_packet_encode(unsigned n, int check, int fec0, int fec1, const uint8_t *msg, uint8_t *pkt);
 int      fxr_packet_decode(unsigned n, int check, int fec0, int fec1, const uint8_t *pkt, uint8_t *msg);
+int      fxr_packet_decode_soft(unsigned n, int check, int fec0, int fec1, uint8_t *soft /* 8 * enc_len, clobbered */, uint8_t *msg);
 int      fxr_fec_supported(int fs);
 
 /* ------------------------------------------------------------------ modem (fxref_modem.c) */
@@ -128,6 +129,8 @@ void     fxr_modem_init(fxr_modem *q, int ms);
 fxr_c32  fxr_modem_mod(fxr_modem *q, unsigned sym);
 /* hard demod: returns symbol, writes remodulated point xhat and phase error imag(r conj(xhat)) */
 unsigned fxr_modem_demod(fxr_modem *q, fxr_c32 r, fxr_c32 *xhat, float *phase_err);
+/* soft decisions of one (carrier-recovered) symbol: bps bytes, MSB of the symbol first; 0 = surely 0 ... 255 = surely 1 */
+void     fxr_modem_demod_soft(int ms, fxr_c32 r, unsigned hard_sym, uint8_t *soft);
 unsigned fxr_qpm_sym_len(unsigned n, int check, int fec0, int fec1, int ms);
 
 /* ------------------------------------------------------------------ frame generator */
@@ -176,6 +179,11 @@ void      fxr_sync_set_threshold(fxr_sync *q, float t);
 /* optional equaliser stage (liquid: FLEXFRAMESYNC_ENABLE_EQ, compiled out by default): 13-tap eqlms at 2 samples/symbol
  * behind the matched filter, trained on the 64 p/n symbols, frozen afterwards; every symbol instant moves 3 symbols later */
 void      fxr_sync_set_equalizer(fxr_sync *q, int on);
+/* soft-decision payload decoding (liquid: flexframesync_decode_payload_soft; off by default, as in the reference's use):
+ * per-bit soft values from the carrier-recovered symbols, soft-input Viterbi */
+void      fxr_sync_set_soft(fxr_sync *q, int on);
+/* the soft values of the most recent frame decoded in soft mode (8 * coded bytes, channel order), for parity tests */
+const uint8_t *fxr_sync_last_soft(const fxr_sync *q, unsigned *n);
 /* introspection used by parity tests: estimates of the most recent frame */
 typedef struct {
     uint64_t start;     /* absolute index (since create/reset_counters) of aligned sample 0 */

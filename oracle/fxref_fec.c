@@ -480,6 +480,101 @@ static void conv_decode(const punc_t *pp, unsigned dec_len, const uint8_t *enc, 
     free(dw);
 }
 
+/* soft-decision form: one byte per coded bit (0 = surely 0 ... 255 = surely 1).  Branch cost of an expected bit e against
+ * a received soft value v: e ? 255 - v : v; punctured positions cost nothing.  Same trellis, same tie rule, same traceback. */
+static void conv_decode_soft(const punc_t *pp, unsigned dec_len, const uint8_t *soft, uint8_t *dec)
+{
+    unsigned n = 8 * dec_len + 6, nb = 0;
+    uint64_t *dw = (uint64_t *)malloc((size_t)n * sizeof(uint64_t));
+    uint32_t pm[64], nm[64];
+    for (int s = 0; s < 64; s++) pm[s] = 1u << 28;
+    pm[0] = 0;
+    for (unsigned t = 0; t < n; t++) {
+        unsigned c = t % pp->p;
+        int ra = -1, rb = -1;
+        if (pp->a[c]) ra = soft[nb++];
+        if (pp->b[c]) rb = soft[nb++];
+        uint64_t d = 0;
+        for (unsigned s = 0; s < 64; s++) {
+            unsigned b = s & 1, p0 = s >> 1, p1 = p0 | 32;
+            unsigned sr0 = ((p0 << 1) | b) & 0x7f, sr1 = ((p1 << 1) | b) & 0x7f;
+            uint32_t m0 = pm[p0], m1 = pm[p1];
+            if (ra >= 0) { m0 += par7(sr0 & V27_A) ? 255u - (unsigned)ra : (unsigned)ra; m1 += par7(sr1 & V27_A) ? 255u - (unsigned)ra : (unsigned)ra; }
+            if (rb >= 0) { m0 += par7(sr0 & V27_B) ? 255u - (unsigned)rb : (unsigned)rb; m1 += par7(sr1 & V27_B) ? 255u - (unsigned)rb : (unsigned)rb; }
+            if (m1 < m0) { nm[s] = m1; d |= 1ull << s; } else nm[s] = m0;
+        }
+        memcpy(pm, nm, sizeof pm);
+        dw[t] = d;
+    }
+    memset(dec, 0, dec_len);
+    unsigned s = 0;
+    for (unsigned t = n; t-- > 0;) {
+        unsigned bit = s & 1;
+        if (t < 8 * dec_len && bit) dec[t >> 3] |= (uint8_t)(0x80u >> (t & 7));
+        s = (s >> 1) | ((unsigned)((dw[t] >> s) & 1ull) << 5);
+    }
+    free(dw);
+}
+
+/* the interleaver's swaps on an array of soft bits (8 per byte, MSB first) */
+static void ilv_pass_soft(uint8_t *x, unsigned n, unsigned M, unsigned N, uint8_t mask)
+{
+    unsigned m = 0, nn = n / 3, n2 = n / 2, j;
+    for (unsigned i = 0; i < n2; i++) {
+        do {
+            j = m * N + nn;
+            m++;
+            if (m == M) { nn = (nn + 1) % N; m = 0; }
+        } while (j >= n2);
+        for (unsigned k = 0; k < 8; k++)
+            if (mask & (0x80u >> k)) { uint8_t t = x[8 * (2 * i) + k]; x[8 * (2 * i) + k] = x[8 * (2 * j + 1) + k]; x[8 * (2 * j + 1) + k] = t; }
+    }
+}
+static void deinterleave_soft(uint8_t *x, unsigned n)
+{
+    unsigned M, N; ilv_dims(n, &M, &N);
+    ilv_pass_soft(x, n, M, N + 8, 0x33); ilv_pass_soft(x, n, M, N + 4, 0x55);
+    ilv_pass_soft(x, n, M, N + 2, 0x0f); ilv_pass_soft(x, n, M, N, 0xff);
+}
+static void soft_to_hard(const uint8_t *soft, unsigned n, uint8_t *out)
+{
+    for (unsigned j = 0; j < n; j++) {
+        unsigned v = 0;
+        for (unsigned b = 0; b < 8; b++) v = (v << 1) | (soft[8 * j + b] > 127 ? 1u : 0u);
+        out[j] = (uint8_t)v;
+    }
+}
+
+/* Soft-decision packet decoder: soft holds 8 * l1 values (modified in place).  A convolutional stage decodes from soft
+ * values as long as nothing before it made hard decisions: the stage nearest the channel (fec1), and fec0 too when fec1 is
+ * FEC_NONE; every other stage takes hard decisions (value > 127) and decodes as fxr_packet_decode does. */
+int fxr_packet_decode_soft(unsigned n, int check, int fec0, int fec1, uint8_t *soft, uint8_t *msg)
+{
+    unsigned cl = fxr_crc_len(check), k = n + cl;
+    unsigned l0 = fxr_fec_enc_len(fec0, k), l1 = fxr_fec_enc_len(fec1, l0);
+    uint8_t *b0 = (uint8_t *)calloc(l1 + 16, 1), *b1 = (uint8_t *)calloc(l1 + 16, 1);
+    const punc_t *p1 = punc_of(fec1), *p0 = punc_of(fec0);
+    int still_soft = 0;
+    deinterleave_soft(soft, l1);
+    if (p1) conv_decode_soft(p1, l0, soft, b1);
+    else if (fec1 == FXR_FEC_NONE) still_soft = 1;
+    else { soft_to_hard(soft, l1, b0); fxr_fec_decode(fec1, l0, b0, b1); }
+    if (still_soft) {
+        deinterleave_soft(soft, l0);
+        if (p0) conv_decode_soft(p0, k, soft, b0);
+        else { soft_to_hard(soft, l0, b1); fxr_fec_decode(fec0, k, b1, b0); }
+    } else {
+        fxr_interleave(b1, l0, 1); fxr_fec_decode(fec0, k, b1, b0);
+    }
+    fxr_scramble(b0, k);
+    uint32_t key = 0;
+    for (unsigned i = 0; i < cl; i++) key = (key << 8) | b0[n + i];
+    memcpy(msg, b0, n);
+    int ok = (fxr_crc_key(check, b0, n) == key);
+    free(b0); free(b1);
+    return ok;
+}
+
 /* ---------------------------------------------------------------- FEC dispatch */
 int fxr_fec_supported(int fs)
 {

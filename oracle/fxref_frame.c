@@ -294,6 +294,8 @@ struct fxr_sync {
     unsigned pay_counter;
     /* optional equaliser */
     int eq_on; fxr_c32 eq_w[FXR_EQ_TAPS], eq_buf[FXR_EQ_TAPS];   /* eq_buf[12] is the newest matched-filter output */
+    /* optional soft-decision decoding */
+    int soft_on; uint8_t *soft, *soft_keep; unsigned soft_n;
 };
 
 fxr_sync *fxr_sync_create(fxr_callback cb, void *ud)
@@ -308,10 +310,12 @@ fxr_sync *fxr_sync_create(fxr_callback cb, void *ud)
 void fxr_sync_destroy(fxr_sync *q)
 {
     if (!q) return;
-    fxr_qdet_destroy(q->det); free(q->pay_sym); free(q->pay_hard); free(q->pay_dec); free(q);
+    fxr_qdet_destroy(q->det); free(q->pay_sym); free(q->pay_hard); free(q->pay_dec); free(q->soft); free(q->soft_keep); free(q);
 }
 void fxr_sync_set_threshold(fxr_sync *q, float t) { fxr_qdet_set_threshold(q->det, t); }
 void fxr_sync_set_equalizer(fxr_sync *q, int on) { q->eq_on = on != 0; }
+void fxr_sync_set_soft(fxr_sync *q, int on) { q->soft_on = on != 0; }
+const uint8_t *fxr_sync_last_soft(const fxr_sync *q, unsigned *n) { if (n) *n = q->soft_n; return q->soft_keep; }
 void fxr_sync_reset(fxr_sync *q)
 {
     fxr_qdet_reset(q->det);
@@ -391,8 +395,22 @@ static void sync_deliver(fxr_sync *q, int payload_valid)
 static void sync_decode_payload(fxr_sync *q)
 {
     unsigned el = fxr_packet_enc_len(q->pay_len, q->check, q->fec0, q->fec1);
-    uint8_t *pkt = (uint8_t *)calloc(el + 1, 1);
     unsigned bps = q->demod.bps;
+    if (q->soft_on) {
+        /* per-bit soft values from the carrier-recovered symbols, in channel order; bits beyond the last symbol do not exist */
+        q->soft = (uint8_t *)realloc(q->soft, 8 * (size_t)el + 8); q->soft_keep = (uint8_t *)realloc(q->soft_keep, 8 * (size_t)el + 8);
+        memset(q->soft, 0, 8 * (size_t)el + 8);
+        for (unsigned j = 0; j < q->pay_sym_len; j++) {
+            uint8_t sb[8];
+            fxr_modem_demod_soft(q->ms, q->pay_sym[j], q->pay_hard[j], sb);
+            for (unsigned b = 0; b < bps; b++) if (j * bps + b < 8 * el) q->soft[j * bps + b] = sb[b];
+        }
+        memcpy(q->soft_keep, q->soft, 8 * (size_t)el); q->soft_n = 8 * el;
+        int oks = fxr_packet_decode_soft(q->pay_len, q->check, q->fec0, q->fec1, q->soft, q->pay_dec);
+        sync_deliver(q, oks);
+        return;
+    }
+    uint8_t *pkt = (uint8_t *)calloc(el + 1, 1);
     for (unsigned j = 0; j < q->pay_sym_len; j++)
         for (unsigned b = 0; b < bps; b++) {
             unsigned k = j * bps + b;

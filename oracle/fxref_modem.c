@@ -7,7 +7,9 @@
  * modem_ask.c, modem_qam.c, modem_qpsk.c]: Gray-coded; PSK points at 2 pi i/M, square/rectangular
  * QAM with unit average energy, ASK4 scaled by 1/sqrt(5).  Hard decisions are taken geometrically
  * (nearest point) so that they need no libm call; the phase error handed to the payload PLL is
- * arg(r conj(xhat)) through fxr_atan2.
+ * imag(r conj(xhat)).  Soft decisions (optional; liquid's modem_demodulate_soft): per coded bit an unsigned byte,
+ * 0 = surely 0, 255 = surely 1, from the difference of the squared distances to the nearest constellation point whose
+ * label carries a 0 / a 1 at that bit.
  */
 #include "fxref.h"
 #include <math.h>
@@ -141,6 +143,66 @@ unsigned fxr_modem_demod(fxr_modem *q, fxr_c32 r, fxr_c32 *xhat, float *phase_er
         *phase_err = fmaf(r.im, xh.re, -(r.re * xh.im));
     }
     return sym;
+}
+
+/* ---------------------------------------------------------------- soft decisions
+ * soft[b], b = 0 .. bps-1 (MSB of the symbol first) = clamp(rint(127 + 16 gamma (d0 - d1)), 0, 255), gamma = 1.2 M
+ * [RECALLED liquid modem_demodulate_soft: gamma = 1.2 M, soft_bit = llr * 16 + 127], d0 / d1 = squared distance from r to
+ * the nearest point with a 0 / a 1 at that bit.  Restatement choices: the search is exhaustive over the M phases for PSK;
+ * ASK and the square / rectangular QAMs are separable, so each axis is searched over its own levels; differential PSK has
+ * no soft form here (as liquid falls back to its hard decision): the hard symbol's bits, as 0 / 255. */
+static inline uint8_t soft_byte(float d0, float d1, float gamma16)
+{
+    float t = rintf(fmaf(d0 - d1, gamma16, 127.0f));
+    if (t < 0.0f) t = 0.0f;
+    if (t > 255.0f) t = 255.0f;
+    return (uint8_t)t;
+}
+/* one axis of an ASK / QAM constellation: L levels (2 i - (L-1)) al, label gray(i), nb bits */
+static void soft_axis(float v, unsigned nb, float al, float gamma16, uint8_t *soft)
+{
+    unsigned L = 1u << nb;
+    float d0[3], d1[3];
+    for (unsigned b = 0; b < nb; b++) { d0[b] = 1e30f; d1[b] = 1e30f; }
+    for (unsigned i = 0; i < L; i++) {
+        float dx = v - (2.0f * (float)i - (float)(L - 1)) * al, d = dx * dx;
+        unsigned g = gray_enc(i);
+        for (unsigned b = 0; b < nb; b++) {
+            if ((g >> (nb - 1 - b)) & 1u) { if (d < d1[b]) d1[b] = d; } else { if (d < d0[b]) d0[b] = d; }
+        }
+    }
+    for (unsigned b = 0; b < nb; b++) soft[b] = soft_byte(d0[b], d1[b], gamma16);
+}
+
+void fxr_modem_demod_soft(int ms, fxr_c32 r, unsigned hard_sym, uint8_t *soft)
+{
+    unsigned bps = fxr_modem_bps(ms);
+    float gamma16 = 1.2f * (float)(1u << bps) * 16.0f;
+    switch (ms) {
+    case FXR_MODEM_DPSK2: case FXR_MODEM_DPSK4: case FXR_MODEM_DPSK8:
+        for (unsigned b = 0; b < bps; b++) soft[b] = ((hard_sym >> (bps - 1 - b)) & 1u) ? 255 : 0;
+        return;
+    case FXR_MODEM_PSK2: case FXR_MODEM_PSK4: case FXR_MODEM_PSK8: case FXR_MODEM_PSK16: {
+        float d0[4], d1[4];
+        for (unsigned b = 0; b < bps; b++) { d0[b] = 1e30f; d1[b] = 1e30f; }
+        for (unsigned i = 0; i < (1u << bps); i++) {
+            fxr_c32 p = psk_point(i, bps);
+            float dx = r.re - p.re, dy = r.im - p.im, d = fmaf(dx, dx, dy * dy);
+            unsigned g = gray_enc(i);
+            for (unsigned b = 0; b < bps; b++) {
+                if ((g >> (bps - 1 - b)) & 1u) { if (d < d1[b]) d1[b] = d; } else { if (d < d0[b]) d0[b] = d; }
+            }
+        }
+        for (unsigned b = 0; b < bps; b++) soft[b] = soft_byte(d0[b], d1[b], gamma16);
+        return; }
+    case FXR_MODEM_ASK4: soft_axis(r.re, 2, 0.447213595f, gamma16, soft); return;
+    case FXR_MODEM_QPSK:                            /* symbol = (re < 0) | (im < 0) << 1: MSB is the imaginary axis */
+        soft_axis(-r.im, 1, (float)M_SQRT1_2, gamma16, soft); soft_axis(-r.re, 1, (float)M_SQRT1_2, gamma16, soft + 1); return;
+    default: {
+        unsigned mi, mq; float al; qam_dims(ms, &mi, &mq, &al);
+        soft_axis(r.re, mi, al, gamma16, soft); soft_axis(r.im, mq, al, gamma16, soft + mi);
+        return; }
+    }
 }
 
 unsigned fxr_qpm_sym_len(unsigned n, int check, int fec0, int fec1, int ms)

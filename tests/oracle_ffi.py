@@ -106,6 +106,9 @@ def lib():
         L.fxr_sync_reset.argtypes = [C.c_void_p]
         L.fxr_sync_set_threshold.argtypes = [C.c_void_p, C.c_float]
         L.fxr_sync_set_equalizer.argtypes = [C.c_void_p, C.c_int]
+        L.fxr_sync_set_soft.argtypes = [C.c_void_p, C.c_int]
+        L.fxr_sync_last_soft.restype = C.c_void_p; L.fxr_sync_last_soft.argtypes = [C.c_void_p, C.POINTER(C.c_uint)]
+        L.fxr_modem_demod_soft.argtypes = [C.c_int, C.c_uint64, C.c_uint, C.c_void_p]
         L.fxr_eq_init_taps.argtypes = [C.c_void_p]
         L.fxr_sync_execute.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
         L.fxr_sync_execute_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint]
@@ -143,7 +146,7 @@ def gen_frame(payload, mod=2, fec0=FEC_CONV_V27, fec1=FEC_NONE, check=CRC_24, he
 
 class Frame:
     __slots__ = ("header", "header_valid", "payload", "payload_valid", "evm", "rssi", "cfo", "framesyms",
-                 "mod_scheme", "mod_bps", "check", "fec0", "fec1", "info")
+                 "mod_scheme", "mod_bps", "check", "fec0", "fec1", "info", "soft")
 
     def __repr__(self):
         return "Frame(hv=%d pv=%d len=%d mod=%d start=%d)" % (
@@ -153,7 +156,7 @@ class Frame:
 class Sync:
     """Oracle flexframesync driven like the reference block (256-sample execute calls)."""
 
-    def __init__(self, threshold=None, equalizer=False):
+    def __init__(self, threshold=None, equalizer=False, soft=False):
         self.L = lib()
         self.frames = []
         self._cb = CALLBACK(self._on_frame)
@@ -162,6 +165,9 @@ class Sync:
             self.L.fxr_sync_set_threshold(self.q, threshold)
         if equalizer:
             self.L.fxr_sync_set_equalizer(self.q, 1)
+        self.soft = bool(soft)
+        if soft:
+            self.L.fxr_sync_set_soft(self.q, 1)
 
     def _on_frame(self, header, hv, payload, plen, pv, st, ud):
         f = Frame()
@@ -178,6 +184,11 @@ class Sync:
         fi = FrameInfo()
         self.L.fxr_sync_last_frame(self.q, C.byref(fi))
         f.info = {k: getattr(fi, k) for k, _ in FrameInfo._fields_}
+        f.soft = None
+        if self.soft and hv:
+            n = C.c_uint(0)
+            p = self.L.fxr_sync_last_soft(self.q, C.byref(n))
+            f.soft = np.frombuffer((C.c_ubyte * n.value).from_address(p), np.uint8).copy() if (p and n.value) else np.zeros(0, np.uint8)
         self.frames.append(f)
         return 0
 

@@ -8,8 +8,8 @@ TOL_EST = 1e-5      # tau, gamma, dphi, phi, pilot estimates (absolute)
 TOL_SYM = 1e-4      # payload symbols after carrier recovery, unit-energy constellation (absolute)
 
 
-def oracle_frames(oracle, x, chunk=256, threshold=None, equalizer=False):
-    s = oracle.Sync(threshold=threshold, equalizer=equalizer)
+def oracle_frames(oracle, x, chunk=256, threshold=None, equalizer=False, soft=False):
+    s = oracle.Sync(threshold=threshold, equalizer=equalizer, soft=soft)
     fr = list(s.execute(x, chunk=chunk))
     s.close()
     return fr

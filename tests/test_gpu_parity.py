@@ -690,3 +690,48 @@ def test_equalizer_stage_on_a_multipath_channel(fx, oracle):
     L.flexframesync_destroy(q)
     of_on = oracle_frames(oracle, xs[0], equalizer=True)
     assert [(f.header_valid, f.payload_valid, f.payload) for f in of_on] == frames[:len(of_on)] and len(frames) >= len(of_on)
+
+
+@pytest.mark.gpu
+def test_soft_decision_demod_and_decode(fx, oracle):
+    """Soft-decision option (north_star "soft demod outputs"; liquid's flexframesync_decode_payload_soft, which the
+    reference never calls -- hence off by default): per-bit soft values from the carrier-recovered symbols for every scheme,
+    soft-input Viterbi for the convolutional stage(s) nearest the channel, hard decisions elsewhere.  Low SNR, so that soft
+    and hard decoding differ.  Stated tolerance: soft values within +-1 of the oracle's (they come out identical -- the
+    test reports it); decoded bytes, validity flags and everything else as in the hard-decision tests."""
+    cases = [(2, 11, 1, 2.5), (27, 15, 1, 9.0), (29, 11, 1, 14.0), (3, 17, 1, 6.5), (1, 11, 7, 1.5), (10, 11, 1, 5.0), (18, 20, 1, 10.0),
+             (28, 1, 11, 12.0), (4, 19, 1, 11.0), (9, 1, 1, 4.0), (11, 11, 1, 9.0), (27, 27, 16, 12.0), (2, 6, 11, 3.0), (2, 11, 11, 1.0)]
+    xs = [fx.synth_stream(150_000, stream_id=600 + i, mod=m, fec0=f0, fec1=f1, payload_len=150 + 7 * i, snr_db=snr)[0] for i, (m, f0, f1, snr) in enumerate(cases)]
+    ctx = fx.RxContext(len(xs), want_framesyms=True, soft_decision=True)
+    gf = ctx.process(xs)
+    n_soft_differs, exact = 0, True
+    for s, x in enumerate(xs):
+        of = oracle_frames(oracle, x, soft=True)
+        mine = [g for g in gf if g["stream"] == s]
+        compare_frames(of, mine)
+        hard = oracle_frames(oracle, x)
+        n_soft_differs += sum(1 for a, b in zip(of, hard) if a.payload != b.payload)
+        for a, b in zip(of, mine):
+            if not a.header_valid: continue
+            assert b["soft_bits"] is not None and len(b["soft_bits"]) == len(a.soft)
+            d = np.abs(a.soft.astype(np.int32) - b["soft_bits"].astype(np.int32)).max() if len(a.soft) else 0
+            assert d <= 1, (cases[s], d)
+            exact = exact and d == 0
+    assert n_soft_differs > 20, "soft and hard decoding never differed: the SNRs are too kind"
+    print("soft values bit-identical:", exact)
+    ctx.close()
+    # default (hard) contexts report no soft values
+    ctx = fx.RxContext(1, want_framesyms=True); g0 = ctx.process([xs[0]]); ctx.close()
+    assert all(g["soft_bits"] is None for g in g0)
+    # continuing blocks in flight + the equaliser at the same time
+    h = np.zeros(6, np.complex64); h[0] = 1.0; h[2] = 0.3j
+    y = np.convolve(xs[1], h)[:len(xs[1])].astype(np.complex64)
+    of = oracle_frames(oracle, y, soft=True, equalizer=True)
+    ctx = fx.RxContext(1, want_framesyms=True, soft_decision=True, equalizer=True); ctx.set_depth(2)
+    got, parts = [], [np.ascontiguousarray(y[a:a + 50_000]) for a in range(0, len(y), 50_000)]
+    for i, pc in enumerate(parts):
+        if i >= 2: got += ctx.results(ctx.collect_raw())
+        ctx.submit_raw([pc.ctypes.data], [len(pc)], False)
+    got += ctx.results(ctx.collect_raw()); got += ctx.results(ctx.collect_raw())
+    compare_frames(of, got)
+    ctx.close()
