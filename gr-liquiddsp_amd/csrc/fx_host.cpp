@@ -151,6 +151,7 @@ struct Slot {
     fxrx_timing timing{};
     double host_submit_ms = 0.0;
     bool any_late = false;
+    uint32_t dec_launched = 0, rs_launched = 0;   // decode waves launched with the chain (lean / Reed-Solomon instance)
     uint32_t kept_hops = 0, kept_cheap = 0, kept_vhops = 0, kept_vfail = 0;   // walk-phase counters of a block whose back part was run again
 };
 
@@ -171,7 +172,7 @@ struct fxrx_ctx_s {
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
     Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
-    uint64_t replays = 0, repairs_host = 0;
+    uint64_t replays = 0, repairs_host = 0, late_decodes = 0;
 };
 
 namespace {
@@ -513,14 +514,15 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
             HIP_OK(fx_launch_softdemod(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_framesyms.p, sl.d_hard.p, sl.d_soft.p, c->d_tables));
             if (c->cfg.want_framesyms) HIP_OK(hipMemcpyAsync(sl.h_soft.p, sl.d_soft.p, 8 * sl.byte_cap, hipMemcpyDeviceToHost, st));
         }
-        const unsigned dec_first = (unsigned)std::min<uint64_t>(chain_slots, fh);
-        HIP_OK(fx_launch_paydec(0, soft, 0, dec_first, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p,
+        // decode: one wave per frame.  The lean instance has no loop (it would double its registers) and an empty workgroup
+        // still has to be given its registers before it can leave: so the grid covers what the last block held plus a margin,
+        // not the list's capacity, and the Reed-Solomon instance (256 registers a wave) is only launched while such frames
+        // keep turning up.  What a launch did not cover is decoded when the block is collected (finish_decode).
+        sl.dec_launched = (unsigned)std::min<uint64_t>(chain_slots, fh);
+        sl.rs_launched = c->rs_hint ? (unsigned)std::min<uint64_t>(chain_slots, c->rs_hint + c->rs_hint / 2 + 64) : 0u;
+        HIP_OK(fx_launch_paydec(0, soft, 0, sl.dec_launched, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p,
                                 sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
-        if (dec_first < chain_slots)
-            HIP_OK(fx_launch_paydec(0, soft, dec_first, chain_slots - dec_first, 8u, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
-                                    sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
-        const unsigned rs_grid = (unsigned)std::min<uint64_t>(chain_slots, std::max<uint64_t>(64, c->rs_hint + c->rs_hint / 2));
-        HIP_OK(fx_launch_paydec(1, soft, 0, rs_grid, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
+        HIP_OK(fx_launch_paydec(1, soft, 0, sl.rs_launched, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
                                 sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[7], st));
         // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
@@ -633,6 +635,32 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
     return 0;
 }
 
+// frames the decode launches of the chain did not cover (more frames than the grid sized from the previous block, or
+// Reed-Solomon frames turning up unannounced): decode them now, on the block's stream, and wait
+static int finish_decode(fxrx_ctx_s *c, Slot &sl)
+{
+    const FxBlockHdr &h = *sl.h_hdr.p;
+    const bool more_plain = h.n_dec_plain > sl.dec_launched, more_rs = h.n_dec_rs > 0 && sl.rs_launched == 0;   // (the Reed-Solomon instance strides: any launch covers all)
+    if (!more_plain && !more_rs) return 0;
+    const uint32_t list_cap = sl.chain_cap + 64 * FX_PLL_CLASSES;
+    FxBlockHdr *hdr_pay = sl.d_hdr.p + 1;
+    const int soft = c->cfg.soft_decision ? 1 : 0;
+    FxPayResult *pres = nullptr;
+#ifdef FX_STAMPS
+    pres = sl.d_pres.p;
+#endif
+    if (more_plain)
+        HIP_OK(fx_launch_paydec(0, soft, sl.dec_launched, h.n_dec_plain - sl.dec_launched, c->dec_waves, sl.st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p,
+                                sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+    if (more_rs)
+        HIP_OK(fx_launch_paydec(1, soft, 0, h.n_dec_rs, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
+                                sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+    HIP_OK(hipStreamSynchronize(sl.st));
+    sl.dec_launched = std::max(sl.dec_launched, h.n_dec_plain); if (more_rs) sl.rs_launched = h.n_dec_rs;
+    c->late_decodes++;
+    return 0;
+}
+
 int fxrx_collect(fxrx_ctx *c)
 {
     if (!c) return FXRX_ERR_ARG;
@@ -650,6 +678,7 @@ int fxrx_collect(fxrx_ctx *c)
         if (flags & FX_BLK_INVALID) { set_err("fxrx_collect: block has no valid start state"); return FXRX_ERR_STATE; }
         if (flags & (FX_BLK_CARRY_OVERFLOW | FX_BLK_NEEDS_REPAIR)) { int r = repair_and_replay(c, sl); if (r) return r; }
     }
+    if (c->cfg.mode != FXRX_MODE_DETECTOR) { int r = finish_decode(c, sl); if (r) return r; }
     sl.timing.host_collectwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
     const FxBlockHdr &h = *sl.h_hdr.p;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
@@ -684,7 +713,8 @@ int fxrx_collect(fxrx_ctx *c)
         if (!S.fresh_start && S.total >= end_total)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
-    c->frames_hint = h.n_frames; c->rs_hint = h.n_dec_rs;
+    c->frames_hint = h.n_frames;
+    c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - c->rs_hint / 8;      // (fades out over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
     float ms = 0;

@@ -64,7 +64,7 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
                injected=n_inj, found=n_found, payload_ok=n_bytes_ok, all_frames_ok=bool(ok),
                ms_per_pass=round(dt * 1e3, 3), msamples_per_s=round(n_streams * n_samples / dt / 1e6, 1),
                ms_per_pass_4_in_flight=round(dtp * 1e3, 3), msamples_per_s_4_in_flight=round(n_streams * n_samples / dtp / 1e6, 1),
-               kernels_ms={k: round(tm[k], 3) for k in ("walk_ms", "paymf_ms", "paypll_ms", "paydec_ms")},
+               kernels_ms={k: round(tm[k], 3) for k in ("walk_ms", "seekverify_ms", "chain_ms", "paymf_ms", "paypll_ms", "paydec_ms")},
                hops=tm["hops"], hops_cheap=tm["hops_cheap"], walk_jobs=tm["walk_jobs"], repairs=tm["repairs"])
     print(json.dumps(out), flush=True)
     ctx.close()
