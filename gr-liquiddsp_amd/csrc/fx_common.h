@@ -183,7 +183,8 @@ enum { FX_BLK_INVALID = 1 /* some stream started from an invalid state: nothing 
 struct FxBlockHdr {                      // device memory, zeroed at submit; mirrored to the host by fx_plan_kernel
     uint32_t n_runs;                     // verification runs emitted (may exceed the capacity: the excess spans are marked bad)
     uint32_t flags;
-    uint32_t n_frames, n_pjobs, n_mfblk, n_dec_plain, n_dec_rs, pad0_;
+    uint32_t n_frames, n_pjobs, n_mfblk, n_dec_plain, n_dec_rs, n_dec_batch;   // n_dec_batch: frames decoded by the batch Viterbi path
+    uint32_t n_vb_items, vb_blk;         // its forward-pass work items (frame, trellis block) / trellis steps per block
     uint32_t pll_cnt[FX_PLL_CLASSES];    // frames per modulation class
     uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
     uint64_t sym_total, byte_total, dw_total, out_total;
@@ -262,7 +263,12 @@ struct FxPayJob {           // one per chain frame; nsym == 0: no payload stage 
     uint32_t pad_;          // 1: the frame has a payload stage
     uint32_t eq;            // 1: equaliser on: taps at chain[chain_idx].eq, symbol instants FX_EQ_DELAY later
     uint32_t chain_idx;     // the frame's slot in the chain table
+    uint32_t vb_off, vb_nblk;   // batch Viterbi path: first work item / number of trellis blocks of this frame
 };
+
+// batch Viterbi: trellis steps of warm-up a block runs before its own region (survivor paths merge within a few
+// constraint lengths; whether they did is verified, see fx_vbpost_kernel)
+#define FX_VB_WARM 96
 
 struct FxPayResult {        // diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases
     uint32_t stamp[8];

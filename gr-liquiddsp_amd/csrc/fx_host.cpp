@@ -48,9 +48,16 @@ extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, 
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T);
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
                                           const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair);
-extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, const FxFrame *chain, const uint32_t *chain_count,
-                                     uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host);
+extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
+                                     const uint32_t *chain_count, uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
+                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
+                                     FxBlockHdr *hdr_host);
+extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
+                                      const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, const FxTables *T);
+extern "C" hipError_t fx_launch_vbfwd(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
+                                      const FxBlockHdr *hdr, const uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena);
+extern "C" hipError_t fx_launch_vbpost(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
+                                       uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena, uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_stats);
 extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                       const FxFrame *chain, float2 *sym_raw, const FxTables *T);
 extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
@@ -138,7 +145,9 @@ struct Slot {
     // device tables
     DevBuf<FxWalkResult> d_wres; DevBuf<FxFrame> d_frames, d_chain; DevBuf<FxVerifyRun> d_runs;
     DevBuf<FxBlockHdr> d_hdr;                // [0] walk-phase counters (zero between blocks), [1] what the payload kernels read
-    DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list;
+    DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list, d_vb_items;
+    DevBuf<uint8_t> d_vb_vec;                // batch Viterbi: metric differences at the start and end of every trellis block
+    uint32_t vb_cap = 0, vb_blk = 0, vb_pre_launched = 0, vb_items_launched = 0;
     DevBuf<FxPayJob> d_pjobs; DevBuf<FxPayResult> d_pres;
     uint32_t run_cap = 0, chain_cap = 0, mf_cap = 0, frame_slots = 0;
     uint64_t sym_cap = 0, byte_cap = 0, dw_cap = 0, out_cap = 0;
@@ -152,6 +161,7 @@ struct Slot {
     double host_submit_ms = 0.0;
     bool any_late = false;
     uint32_t dec_launched = 0, rs_launched = 0;   // decode waves launched with the chain (lean / Reed-Solomon instance)
+    bool force_noskip = false;               // walk this block with the exact detector on every hop (nothing to verify)
     uint32_t kept_hops = 0, kept_cheap = 0, kept_vhops = 0, kept_vfail = 0;   // walk-phase counters of a block whose back part was run again
 };
 
@@ -169,10 +179,14 @@ struct fxrx_ctx_s {
     hipEvent_t carry_reader[3] = { nullptr, nullptr, nullptr };   // payload MF of the newest block that reads carry[i]
     uint32_t verify_per = 4;             // hops per verification run (adapted to the traffic)
     uint64_t frames_hint = 0, rs_hint = 0;   // frames / Reed-Solomon frames of the last collected block (size the PLL / decode grids)
+    uint64_t plain_hint = 0, batch_hint = 0, vb_items_hint = 0, vb_steps_hint = 0;   // likewise: frames of the wave-per-frame / batch decoders, trellis blocks, trellis steps
+    bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
+    bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
     Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
     uint64_t replays = 0, repairs_host = 0, late_decodes = 0;
+    unsigned noskip_left = 0;            // blocks still to be walked with the exact detector on every hop (after a verification failure)
 };
 
 namespace {
@@ -295,6 +309,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_DEC_WAVES")) c->dec_waves = (unsigned)std::min(8, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     if (upload_tables(c) != 0) return fail();
@@ -396,7 +411,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
             j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && cont ? (uint64_t)sn.carry_bound : 0u));
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
-            j.no_skip = (detect || !c->skip_seek) ? 1u : 0u;
+            j.no_skip = (detect || !c->skip_seek || sl.force_noskip) ? 1u : 0u;
             j.state_in = (first && cont) ? sd.state_in : nullptr;
             j.stream = s; j.verify_per = c->verify_per; j.eq = (!detect && c->cfg.equalizer) ? 1u : 0u;
             (first && cont ? late : early).push_back((uint32_t)jobs.size());
@@ -420,6 +435,10 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     sl.dw_cap = detect ? 0 : (span / 2) * 6 + 200ull * chain_slots + 64;
     sl.out_cap = (span / 2) * 3 / 4 + 16ull * chain_slots + 64;
     sl.mf_cap = (uint32_t)std::min<uint64_t>(span / 2 / 1024 + chain_slots + 16, 0x7fffffffu);
+    // batch Viterbi: trellis steps per block from the traffic of the last block (enough blocks to fill the chip, few enough to
+    // keep the warm-up cheap); its work items number at most (coded bits) / blk + one per frame + padding per code class
+    sl.vb_blk = (detect || c->cfg.soft_decision || !c->batch_viterbi) ? 0u : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(c->depth > 1 ? 512 : 192, ((c->vb_steps_hint / 65536 + 63) / 64) * 64));
+    sl.vb_cap = sl.vb_blk ? (uint32_t)std::min<uint64_t>(3 * span / sl.vb_blk + chain_slots + 512, 0x7fffffffu) : 1u;
     if (sl.sym_cap >= (1ull << 32) || sl.dw_cap >= (1ull << 32)) { set_err("fxrx_submit: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
 
     // ---- 2. memory ----
@@ -430,10 +449,11 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (sl.hp_desc.reserve(desc_bytes) || sl.d_desc.reserve(desc_bytes) || sl.d_wres.reserve(NJ + NS) || sl.d_frames.reserve(frame_slots) ||
         sl.d_runs.reserve(sl.run_cap) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
-        sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(2 * (size_t)list_cap)) return FXRX_ERR_HIP;
+        sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(3 * (size_t)list_cap)) return FXRX_ERR_HIP;
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_framesyms.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
                     sl.d_bufA.reserve(sl.byte_cap) || sl.d_bufB.reserve(sl.byte_cap) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.want_framesyms && sl.h_framesyms.reserve(sl.sym_cap)) return FXRX_ERR_HIP;
+    if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_cap) || (sl.vb_blk && sl.d_vb_vec.reserve(128 * (size_t)sl.vb_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.soft_decision && (sl.d_soft.reserve(8 * sl.byte_cap) || (c->cfg.want_framesyms && sl.h_soft.reserve(8 * sl.byte_cap)))) return FXRX_ERR_HIP;
 #ifdef FX_STAMPS
     if (!detect && sl.d_pres.reserve(chain_slots)) return FXRX_ERR_HIP;
@@ -457,7 +477,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
     }
     HIP_OK(hipEventRecord(sl.ev[1], st));
-    if (!detect && c->skip_seek)
+    if (!detect && c->skip_seek && !sl.force_noskip)
         HIP_OK(fx_launch_seekverify(4u * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables));
     HIP_OK(hipEventRecord(sl.ev[2], st));
     // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
@@ -487,8 +507,8 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
         HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u));
     HIP_OK(hipEventRecord(sl.ev[3], st));
     c->prev_chain = sl.ev[3];
-    HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
-                          sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap, hdr, hdr_pay, sl.h_hdr.p));
+    HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
+                          sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap, sl.d_vb_items.p, sl.vb_cap, hdr, hdr_pay, sl.h_hdr.p));
     HIP_OK(hipEventRecord(sl.ev[4], st));
     if (!detect) {
         // grids stride over lists whose lengths only the device knows; size them from what the last block held
@@ -518,12 +538,21 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
         // still has to be given its registers before it can leave: so the grid covers what the last block held plus a margin,
         // not the list's capacity, and the Reed-Solomon instance (256 registers a wave) is only launched while such frames
         // keep turning up.  What a launch did not cover is decoded when the block is collected (finish_decode).
-        sl.dec_launched = (unsigned)std::min<uint64_t>(chain_slots, fh);
+        sl.dec_launched = c->first_block ? chain_slots : (unsigned)std::min<uint64_t>(chain_slots, c->plain_hint + c->plain_hint / 2 + 64);
         sl.rs_launched = c->rs_hint ? (unsigned)std::min<uint64_t>(chain_slots, c->rs_hint + c->rs_hint / 2 + 64) : 0u;
         HIP_OK(fx_launch_paydec(0, soft, 0, sl.dec_launched, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p,
                                 sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
         HIP_OK(fx_launch_paydec(1, soft, 0, sl.rs_launched, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
                                 sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+        // batch Viterbi path (most frames: hard decisions, convolutional fec0): front part, forward pass over trellis blocks, back part
+        if (sl.vb_blk) {
+            sl.vb_pre_launched = c->first_block ? chain_slots : (unsigned)std::min<uint64_t>(chain_slots, c->batch_hint + c->batch_hint / 2 + 64);
+            sl.vb_items_launched = c->first_block ? sl.vb_cap : (unsigned)std::min<uint64_t>(sl.vb_cap, c->vb_items_hint + c->vb_items_hint / 2 + 1024);
+            HIP_OK(fx_launch_vbpre(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
+            HIP_OK(fx_launch_vbfwd(0, sl.vb_items_launched, st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufB.p, sl.d_dw.p, sl.d_vb_vec.p));
+            HIP_OK(fx_launch_vbpost(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p,
+                                    sl.d_vb_vec.p, sl.h_out.p, sl.h_recs.p, hdr_pay));
+        } else sl.vb_pre_launched = sl.vb_items_launched = 0;
         HIP_OK(hipEventRecord(sl.ev[7], st));
         // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
         if (c->cfg.want_framesyms)
@@ -547,6 +576,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     Slot &sl = *c->slots[c->head];
     sl.out.clear(); sl.timing = fxrx_timing{};
     sl.kept_hops = sl.kept_cheap = sl.kept_vhops = sl.kept_vfail = 0;
+    sl.force_noskip = c->noskip_left > 0; if (c->noskip_left) c->noskip_left--;
     sl.seq = c->seq;
     sl.x.assign(NS, nullptr); sl.n.assign(n_samples, n_samples + NS); sl.snap.assign(NS, StreamSnap{});
     if (sl.d_in.size() < NS) sl.d_in.resize(NS);
@@ -587,14 +617,20 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
 {
     const unsigned NS = c->cfg.n_streams;
     const unsigned nslots = c->depth + 1;
-    for (int round = 0; round < 4; round++) {
+    for (int round = 0; round < 6; round++) {
         for (auto &s : c->slots) if (s->busy) HIP_OK(hipStreamSynchronize(s->st));
         const uint32_t flags = sl.h_hdr.p->flags;
         if (flags & FX_BLK_NEEDS_REPAIR) {
             c->repairs_host++;
             const FxBlockHdr &h0 = *sl.h_hdr.p;         // the walk-phase counters are zeroed with the first plan kernel: keep them
             sl.kept_hops += h0.hops; sl.kept_cheap += h0.hops_cheap; sl.kept_vhops += h0.verify_hops; sl.kept_vfail += h0.verify_failures;
-            if (enqueue_back(c, sl, true)) return FXRX_ERR_HIP;
+            if (!sl.force_noskip && c->cfg.mode != FXRX_MODE_DETECTOR && c->skip_seek && h0.verify_failures) {
+                // Skipped hops on which the exact detector fires (weak preambles, false alarms: low SNR).  Walk the block
+                // again, all segments in parallel, with the exact detector on every hop -- exact by itself, nothing to
+                // verify -- and stay in that mode for the next blocks: the channel will not have improved meanwhile.
+                sl.force_noskip = true; c->noskip_left = 32;
+                if (enqueue_block(c, sl)) return FXRX_ERR_HIP;
+            } else if (enqueue_back(c, sl, true)) return FXRX_ERR_HIP;   // what is left (a hand-off target not in the next list) the full-size chain kernel walks
             continue;                                   // (its tail may in turn overflow the carry buffer)
         }
         if (!(flags & FX_BLK_CARRY_OVERFLOW)) break;
@@ -641,7 +677,8 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
 {
     const FxBlockHdr &h = *sl.h_hdr.p;
     const bool more_plain = h.n_dec_plain > sl.dec_launched, more_rs = h.n_dec_rs > 0 && sl.rs_launched == 0;   // (the Reed-Solomon instance strides: any launch covers all)
-    if (!more_plain && !more_rs) return 0;
+    const bool more_batch = h.n_dec_batch > sl.vb_pre_launched || h.n_vb_items > sl.vb_items_launched;
+    if (!more_plain && !more_rs && !more_batch) return 0;
     const uint32_t list_cap = sl.chain_cap + 64 * FX_PLL_CLASSES;
     FxBlockHdr *hdr_pay = sl.d_hdr.p + 1;
     const int soft = c->cfg.soft_decision ? 1 : 0;
@@ -655,6 +692,13 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
     if (more_rs)
         HIP_OK(fx_launch_paydec(1, soft, 0, h.n_dec_rs, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
                                 sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+    if (more_batch) {       // (all three parts again, for all of the path's frames: they are idempotent)
+        HIP_OK(fx_launch_vbpre(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
+        HIP_OK(fx_launch_vbfwd(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufB.p, sl.d_dw.p, sl.d_vb_vec.p));
+        HIP_OK(fx_launch_vbpost(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_vb_vec.p,
+                                sl.h_out.p, sl.h_recs.p, hdr_pay));
+        sl.vb_pre_launched = h.n_dec_batch; sl.vb_items_launched = h.n_vb_items;
+    }
     HIP_OK(hipStreamSynchronize(sl.st));
     sl.dec_launched = std::max(sl.dec_launched, h.n_dec_plain); if (more_rs) sl.rs_launched = h.n_dec_rs;
     c->late_decodes++;
@@ -683,6 +727,7 @@ int fxrx_collect(fxrx_ctx *c)
     const FxBlockHdr &h = *sl.h_hdr.p;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
     sl.out.resize(h.n_frames);
+    uint64_t vb_rep = 0;                       // trellis blocks the batch Viterbi path had to run again (hand-over check failed)
     for (uint32_t i = 0; i < h.n_frames; i++) {
         const FxOutRec &r = sl.h_recs.p[i];
         fxrx_frame &f = sl.out[i].f; std::memset(&f, 0, sizeof f);
@@ -696,6 +741,7 @@ int fxrx_collect(fxrx_ctx *c)
             f.mod_scheme = r.ms; f.mod_bps = r.bps; f.check = r.check; f.fec0 = r.fec0; f.fec1 = r.fec1;
             f.payload_len = r.pay_len; f.num_framesyms = r.nsym;
             f.payload = sl.h_out.p + r.out_off; f.payload_valid = (int)r.payload_valid;
+            vb_rep += r.status >> 8;
             f.evm_sum = r.evm_sum; f.evm_db = 10.0f * log10f(r.evm_sum / (float)(r.nsym ? r.nsym : 1));
             f.framesyms = c->cfg.want_framesyms ? (const fx_complex *)(sl.h_framesyms.p + r.sym_off) : nullptr;
             if (c->cfg.soft_decision && c->cfg.want_framesyms) {
@@ -713,7 +759,8 @@ int fxrx_collect(fxrx_ctx *c)
         if (!S.fresh_start && S.total >= end_total)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
-    c->frames_hint = h.n_frames;
+    c->frames_hint = h.n_frames; c->plain_hint = h.n_dec_plain; c->batch_hint = h.n_dec_batch; c->vb_items_hint = h.n_vb_items;
+    c->vb_steps_hint = (uint64_t)h.n_vb_items * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
     c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - c->rs_hint / 8;      // (fades out over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
@@ -730,6 +777,7 @@ int fxrx_collect(fxrx_ctx *c)
     t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs; t.frames = h.n_frames;
     t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops + sl.kept_vhops; t.verify_failures = h.verify_failures + sl.kept_vfail;
     t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays + c->repairs_host;
+    t.vb_blocks = h.n_vb_items; t.vb_repairs = vb_rep; t.late_decodes = c->late_decodes;
     sl.busy = false; c->last = &sl;
     c->tail = (c->tail + 1) % nslots; c->inflight--;
     return (int)sl.out.size();

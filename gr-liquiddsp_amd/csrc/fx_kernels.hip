@@ -1223,7 +1223,7 @@ extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, 
 // modulation class, each padded to whole waves) and the two decode lists (with / without a Reed-Solomon stage).  It also
 // writes one FxOutRec per frame straight into pinned host memory and mirrors the block header there.
 #define PLAN_THREADS 256
-#define PLAN_NV 6
+#define PLAN_NV 7
 
 __device__ __forceinline__ unsigned pll_class(unsigned ms)
 {
@@ -1260,20 +1260,24 @@ __device__ __forceinline__ void plan_scan(uint32_t (&v)[PLAN_NV], uint32_t (&tot
 // hdr: the block's walk-phase counters (zeroed again at the end, for the slot's next block); hdr_pay: what the payload kernels
 // read; hdr_host: the host's copy.
 extern "C" __global__ __launch_bounds__(PLAN_THREADS)
-void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, const FxFrame *chain, const uint32_t *chain_count,
+void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain, const uint32_t *chain_count,
                     uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                    uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host)
+                    uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
+                    FxBlockHdr *hdr_host)
 {
+    // vb_blk: trellis steps per block of the batch Viterbi path (0: path off, e.g. soft decisions); vb_items: [frame | block] x vb_cap
+    __shared__ uint32_t vbc_cnt[7], vbc_base[8], vbc_fill[7];
+    if (threadIdx.x < 7) { vbc_cnt[threadIdx.x] = 0; vbc_fill[threadIdx.x] = 0; }
     __shared__ uint32_t ws[PLAN_THREADS / 64][PLAN_NV];
-    __shared__ uint32_t cls_cnt[FX_PLL_CLASSES], cls_base[FX_PLL_CLASSES + 1], cls_fill[FX_PLL_CLASSES], dec_cnt[2], dec_fill[2];
+    __shared__ uint32_t cls_cnt[FX_PLL_CLASSES], cls_base[FX_PLL_CLASSES + 1], cls_fill[FX_PLL_CLASSES], dec_cnt[3], dec_fill[3];
     const int tid = threadIdx.x;
     if (tid < FX_PLL_CLASSES) { cls_cnt[tid] = 0; cls_fill[tid] = 0; }
-    if (tid < 2) { dec_cnt[tid] = 0; dec_fill[tid] = 0; }
+    if (tid < 3) { dec_cnt[tid] = 0; dec_fill[tid] = 0; }
     // 1. frames before each stream
     uint32_t run = 0;
     for (uint32_t s0 = 0; s0 < nstreams; s0 += PLAN_THREADS) {
         const uint32_t sidx = s0 + tid;
-        uint32_t v[PLAN_NV] = { sidx < nstreams ? chain_count[sidx] : 0u, 0, 0, 0, 0, 0 }, tot[PLAN_NV];
+        uint32_t v[PLAN_NV] = { sidx < nstreams ? chain_count[sidx] : 0u, 0, 0, 0, 0, 0, 0 }, tot[PLAN_NV];
         plan_scan(v, tot, ws);
         if (sidx < nstreams) stream_base[sidx] = run + v[0];
         run += tot[0];
@@ -1282,13 +1286,13 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     if (tid == 0) stream_base[nstreams] = N;
     __threadfence(); __syncthreads(); __threadfence();
     // 2. sizes, offsets, jobs, records, matched-filter items
-    uint32_t sym_run = 0, byte_run = 0, dw_run = 0, out_run = 0, mf_run = 0, npj = 0;
+    uint32_t sym_run = 0, byte_run = 0, dw_run = 0, out_run = 0, mf_run = 0, npj = 0, vb_run = 0;
     for (uint32_t g0 = 0; g0 < N; g0 += PLAN_THREADS) {
         const uint32_t g = g0 + tid;
         const bool live = g < N;
         const FxFrame *fp = chain; uint32_t sidx = 0;
-        uint32_t v[PLAN_NV] = { 0, 0, 0, 0, 0, 0 }, tot[PLAN_NV], bps = 0, k = 0, l0 = 0, l1 = 0, nblk = 0;
-        bool valid = false;
+        uint32_t v[PLAN_NV] = { 0, 0, 0, 0, 0, 0, 0 }, tot[PLAN_NV], bps = 0, k = 0, l0 = 0, l1 = 0, nblk = 0, vnb = 0;
+        bool valid = false, batch = false;
         if (live) {
             uint32_t lo = 0, hi = nstreams;                                  // stream_base[lo] <= g < stream_base[hi]
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (stream_base[mid] <= g) lo = mid; else hi = mid; }
@@ -1305,11 +1309,15 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
                 v[2] = ((8u * max(l0, k) + 6u + 63u) & ~63u) + 64u;          // whole 64-step chunks, lane-major
                 v[3] = (plen + 15u) & ~15u;
                 v[4] = nblk; v[5] = 1u;
+                // batch Viterbi path: hard decisions, fec0 a K = 7 convolutional code, fec1 neither convolutional nor Reed-Solomon
+                batch = vb_blk && conv_p(fp->fec0) && !conv_p(fp->fec1) && fp->fec1 != FX_FEC_RS_M8;
+                if (batch) { vnb = (8u * k + 6u + vb_blk - 1u) / vb_blk; v[6] = vnb; }
             }
         }
         plan_scan(v, tot, ws);
         const uint32_t sym_off = sym_run + v[0], byte_off = byte_run + v[1], dw_off = dw_run + v[2], out_off = out_run + v[3], mf_off = mf_run + v[4];
-        sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; npj += tot[5];
+        const uint32_t vb_off = vb_run + v[6];
+        sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; npj += tot[5]; vb_run += tot[6];
         if (live) {
             const FxStreamDesc &sd = streams[sidx];
             FxPayJob j;
@@ -1318,7 +1326,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             j.nsym = valid ? fp->pay_sym_len : 0u; j.sym_off = sym_off;
             j.pay_len = fp->pay_len; j.check = fp->check; j.fec0 = fp->fec0; j.fec1 = fp->fec1; j.k = k; j.l0 = l0; j.l1 = l1;
             j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = valid ? 1u : 0u;
-            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain);
+            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain); j.vb_off = vb_off; j.vb_nblk = vnb;
             pjobs[g] = j;
             // the record goes to pinned host memory: assemble it in registers, send it as eight 16-byte stores
             union { FxOutRec r; uint4 q[sizeof(FxOutRec) / 16]; } u;
@@ -1339,7 +1347,8 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             if (valid) {
                 for (uint32_t c = 0; c < nblk; c++) if (mf_off + c < mf_cap) { mf_job[mf_off + c] = g; mf_c0[mf_off + c] = c * 1024u; }
                 atomicAdd(&cls_cnt[pll_class(fp->ms)], 1u);
-                atomicAdd(&dec_cnt[(fp->fec0 == FX_FEC_RS_M8 || fp->fec1 == FX_FEC_RS_M8) ? 1 : 0], 1u);
+                atomicAdd(&dec_cnt[batch ? 2 : ((fp->fec0 == FX_FEC_RS_M8 || fp->fec1 == FX_FEC_RS_M8) ? 1 : 0)], 1u);
+                if (batch) atomicAdd(&vbc_cnt[conv_p(fp->fec0) - 1], vnb);
             }
         }
     }
@@ -1349,10 +1358,15 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
         uint32_t b = 0;
         for (int c = 0; c < FX_PLL_CLASSES; c++) { cls_base[c] = b; b += (cls_cnt[c] + 63u) & ~63u; }
         cls_base[FX_PLL_CLASSES] = b;
+        uint32_t vb = 0;
+        for (int c = 0; c < 7; c++) { vbc_base[c] = vb; vb += (vbc_cnt[c] + 63u) & ~63u; }
+        vbc_base[7] = vb;
     }
     __syncthreads();
     const uint32_t pll_slots = min(cls_base[FX_PLL_CLASSES], list_cap);
     for (uint32_t i = tid; i < pll_slots; i += PLAN_THREADS) pll_list[i] = 0xFFFFFFFFu;
+    const uint32_t vb_slots = min(vbc_base[7], vb_cap);
+    for (uint32_t i = tid; i < vb_slots; i += PLAN_THREADS) vb_items[i] = 0xFFFFFFFFu;
     __threadfence(); __syncthreads(); __threadfence();
     for (uint32_t g = tid; g < N; g += PLAN_THREADS) {
         const FxPayJob &j = pjobs[g];
@@ -1360,15 +1374,21 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
         const unsigned c = pll_class(j.ms);
         const uint32_t pp = cls_base[c] + atomicAdd(&cls_fill[c], 1u);
         if (pp < list_cap) pll_list[pp] = g;
-        const int rs = (j.fec0 == FX_FEC_RS_M8 || j.fec1 == FX_FEC_RS_M8) ? 1 : 0;
+        const int rs = j.vb_nblk ? 2 : ((j.fec0 == FX_FEC_RS_M8 || j.fec1 == FX_FEC_RS_M8) ? 1 : 0);
         const uint32_t dp = atomicAdd(&dec_fill[rs], 1u);
         if (dp < list_cap) dec_list[(size_t)rs * list_cap + dp] = g;
+        if (j.vb_nblk) {                                                       // its trellis blocks, among those of the same code
+            const int vc = conv_p(j.fec0) - 1;
+            const uint32_t at = vbc_base[vc] + atomicAdd(&vbc_fill[vc], j.vb_nblk);
+            for (uint32_t b = 0; b < j.vb_nblk; b++) if (at + b < vb_cap) { vb_items[at + b] = g; vb_items[vb_cap + at + b] = b; }
+        }
     }
     __syncthreads();
     // 4. block header: for the payload kernels, for the host; the walk-phase counters are zeroed for the slot's next block
     if (tid == 0) {
         FxBlockHdr h = *hdr;
         h.n_frames = N; h.n_pjobs = npj; h.n_mfblk = min(mf_run, mf_cap); h.n_dec_plain = dec_cnt[0]; h.n_dec_rs = dec_cnt[1];
+        h.n_dec_batch = dec_cnt[2]; h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk;
         for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = cls_cnt[c]; h.pll_base[c] = cls_base[c]; }
         h.pll_base[FX_PLL_CLASSES] = cls_base[FX_PLL_CLASSES];
         h.sym_total = sym_run; h.byte_total = byte_run; h.dw_total = dw_run; h.out_total = out_run;
@@ -1383,12 +1403,13 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     }
 }
 
-extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, const FxFrame *chain, const uint32_t *chain_count,
-                                     uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host)
+extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
+                                     const uint32_t *chain_count, uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
+                                     uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
+                                     FxBlockHdr *hdr_host)
 {
-    hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, eq, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0, mf_cap,
-                       pll_list, dec_list, list_cap, hdr, hdr_pay, hdr_host);
+    hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, eq, vb_blk, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0,
+                       mf_cap, pll_list, dec_list, list_cap, vb_items, vb_cap, hdr, hdr_pay, hdr_host);
     return hipGetLastError();
 }
 
@@ -2144,6 +2165,40 @@ __device__ __forceinline__ uint32_t crc_wave(uint32_t poly_rev, uint32_t mask, c
 // workgroups keep a block's decode waves together on few CUs instead of sprinkling one wave over every CU, which
 // matters to the walker of the next block (its workgroups need a whole, empty register file each).
 #define DEC_MAX_WAVES 8
+// de-whiten, CRC, copy out (the payload goes straight into the host's result arena); A: the k decoded bytes
+__device__ __forceinline__ void dec_tail(const FxPayJob &job, uint32_t jf, uint8_t *A, int lane, uint8_t *out, FxOutRec *recs, uint32_t status)
+{
+    const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
+    for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    for (uint32_t j = lane; 4 * j < job.pay_len; j += DEC_THREADS) {                // out_off is a multiple of 16
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) if (4 * j + b < job.pay_len) w |= (uint32_t)A[4 * j + b] << (8 * b);
+        reinterpret_cast<uint32_t *>(out + job.out_off)[j] = w;
+    }
+    const uint32_t cl = job.k - job.pay_len;
+    uint32_t rx = 0, key = 0;
+    for (uint32_t i = 0; i < cl; i++) rx = (rx << 8) | A[job.pay_len + i];
+    switch (job.check) {
+    case FX_CRC_CHECKSUM: {
+        uint32_t sm = 0;
+        for (uint32_t i = lane; i < job.pay_len; i += DEC_THREADS) sm += A[i];
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) sm += (uint32_t)__shfl_xor((int)sm, m, 64);
+        key = (~sm + 1u) & 0xff; break; }
+    case FX_CRC_8:  key = crc_wave(0xE0u, 0xFFu, A, job.pay_len, lane); break;
+    case FX_CRC_16: key = crc_wave(0xA001u, 0xFFFFu, A, job.pay_len, lane); break;
+    case FX_CRC_24: key = crc_wave(0xD3B6BAu, 0xFFFFFFu, A, job.pay_len, lane); break;
+    case FX_CRC_32: key = crc_wave(0xEDB88320u, 0xFFFFFFFFu, A, job.pay_len, lane); break;
+    default: key = 0; break;
+    }
+    if (lane == 0) {
+        recs[jf].payload_valid = (key == rx) ? 1u : 0u;
+        recs[jf].status = status;
+    }
+}
+
 // one frame, one wave.  SOFT: decoding from per-bit soft values (fx_softdemod_kernel wrote them, 8 per packet byte):
 // a convolutional stage decodes from soft values as long as nothing before it took hard decisions -- the stage nearest the
 // channel (fec1), and fec0 too when fec1 is FEC_NONE; every other stage takes hard decisions (value > 127).
@@ -2227,38 +2282,7 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(4);
     }
-    // 4. de-whiten, CRC, copy out (the payload goes straight into the host's result arena)
-    const uint8_t mask[4] = { 0xb4, 0x6a, 0x8b, 0xc5 };
-    for (uint32_t j = lane; j < job.k; j += DEC_THREADS) A[j] ^= mask[j & 3];
-    __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    for (uint32_t j = lane; 4 * j < job.pay_len; j += DEC_THREADS) {                // out_off is a multiple of 16
-        uint32_t w = 0;
-#pragma unroll
-        for (int b = 0; b < 4; b++) if (4 * j + b < job.pay_len) w |= (uint32_t)A[4 * j + b] << (8 * b);
-        reinterpret_cast<uint32_t *>(out + job.out_off)[j] = w;
-    }
-    {
-        const uint32_t cl = job.k - job.pay_len;
-        uint32_t rx = 0, key = 0;
-        for (uint32_t i = 0; i < cl; i++) rx = (rx << 8) | A[job.pay_len + i];
-        switch (job.check) {
-        case FX_CRC_CHECKSUM: {
-            uint32_t sm = 0;
-            for (uint32_t i = lane; i < job.pay_len; i += DEC_THREADS) sm += A[i];
-#pragma unroll
-            for (int m = 1; m < 64; m <<= 1) sm += (uint32_t)__shfl_xor((int)sm, m, 64);
-            key = (~sm + 1u) & 0xff; break; }
-        case FX_CRC_8:  key = crc_wave(0xE0u, 0xFFu, A, job.pay_len, lane); break;
-        case FX_CRC_16: key = crc_wave(0xA001u, 0xFFFFu, A, job.pay_len, lane); break;
-        case FX_CRC_24: key = crc_wave(0xD3B6BAu, 0xFFFFFFu, A, job.pay_len, lane); break;
-        case FX_CRC_32: key = crc_wave(0xEDB88320u, 0xFFFFFFFFu, A, job.pay_len, lane); break;
-        default: key = 0; break;
-        }
-        if (lane == 0) {
-            recs[jf].payload_valid = (key == rx) ? 1u : 0u;
-            recs[jf].status = status;
-        }
-    }
+    dec_tail(job, jf, A, lane, out, recs, status);
     FX_STAMP(5);
 }
 
@@ -2294,6 +2318,331 @@ extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wav
     if (with_rs) { if (soft) FX_DEC_LAUNCH(true, true); else FX_DEC_LAUNCH(true, false); }
     else { if (soft) FX_DEC_LAUNCH(false, true); else FX_DEC_LAUNCH(false, false); }
 #undef FX_DEC_LAUNCH
+    return hipGetLastError();
+}
+
+// ===================================================================== payload: batch Viterbi (lane per trellis block)
+// The wave-per-frame decoder above keeps one trellis state per lane: every add-compare-select step pays a lane exchange and
+// a dependent chain, ~13 instructions for one trellis step of one frame.  Here a LANE runs the whole 64-state trellis of a
+// stretch of one frame -- 64 path metrics in registers, 32 butterflies of straight-line VALU code per step, no lane exchange
+// -- so one instruction serves 64 stretches: ~5 instructions per state and step, and nothing in a step depends on anything
+// but the previous step.
+//
+// Enough lanes come from cutting every frame's trellis into blocks of `blk` steps that run in parallel.  A block other than
+// the first does not know its start metrics; it runs FX_VB_WARM steps of warm-up from all-equal metrics first.  Survivor
+// paths merge within a few constraint lengths, after which the metric DIFFERENCES -- all that add-compare-select decisions
+// depend on -- are the true ones.  That is not assumed but verified: every block records its metric differences at the start
+// of its region and at its end; fx_vbpost_kernel checks block b's start against block b-1's end and, on a mismatch, runs
+// block b again from the true differences.  Decisions are then exactly the sequential decoder's, for any block size.
+//
+// Frames that take this path (fx_plan_kernel): hard decisions, fec0 a K = 7 convolutional code (any puncturing), fec1 not.
+//   fx_vbpre_kernel   wave per frame   symbols -> packet bytes, de-interleave, fec1, de-interleave: the coded bits
+//   fx_vbfwd_kernel   lane per block   forward pass, one 64-bit decision word per trellis step
+//   fx_vbpost_kernel  wave per frame   verification (+ repair), chunk-parallel traceback, de-whitening, CRC, payload out
+__device__ __forceinline__ constexpr unsigned vb_expect(unsigned j)      // expected code bits (A | B << 1) of the branch j -> 2j
+{
+    const unsigned sr = (j << 1) & 0x7fu;
+    return ((unsigned)__builtin_popcount(sr & 0x6du) & 1u) | (((unsigned)__builtin_popcount(sr & 0x4fu) & 1u) << 1);
+}
+
+struct VbState {
+    uint32_t P[64];            // path metrics
+};
+
+// metric differences to the smallest, as bytes (a K = 7 trellis keeps them within a dozen once every state is reachable)
+__device__ __forceinline__ void vb_save_vec(const uint32_t (&P)[64], uint8_t *dst)
+{
+    uint32_t mn = P[0];
+#pragma unroll
+    for (int i = 1; i < 64; i++) mn = min(mn, P[i]);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) w |= min(P[4 * i + b] - mn, 255u) << (8 * b);
+        d[i] = w;
+    }
+}
+
+// One butterfly, fully unrolled by the caller: predecessors j and j + 32, successors 2j and 2j + 1.  Keys are (metric << 1)
+// + 2 cost (+ 1 for the predecessor with MSB 1): the minimum is the survivor, "equal -> predecessor with MSB 0", and its
+// LSB is the decision bit, shifted into the history word by one v_alignbit.
+template <int J>
+__device__ __forceinline__ void vb_butterfly(const uint32_t (&P)[64], uint32_t (&N)[64], const uint32_t (&c2)[4], const uint32_t (&c2p)[4], uint32_t &hist)
+{
+    constexpr unsigned e = vb_expect(J), ne = 3u - e;
+    const uint32_t a0 = (P[J] << 1) + c2[e],  a1 = (P[J + 32] << 1) + c2p[ne];
+    const uint32_t b0 = (P[J] << 1) + c2[ne], b1 = (P[J + 32] << 1) + c2p[e];
+    const uint32_t m0 = min(a0, a1), m1 = min(b0, b1);
+    hist = __builtin_amdgcn_alignbit(m0, hist, 1); N[2 * J] = m0 >> 1;
+    hist = __builtin_amdgcn_alignbit(m1, hist, 1); N[2 * J + 1] = m1 >> 1;
+}
+template <int J0>
+__device__ __forceinline__ void vb_half(const uint32_t (&P)[64], uint32_t (&N)[64], const uint32_t (&c2)[4], const uint32_t (&c2p)[4], uint32_t &hist)
+{
+    vb_butterfly<J0 + 0>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 1>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 2>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 3>(P, N, c2, c2p, hist);
+    vb_butterfly<J0 + 4>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 5>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 6>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 7>(P, N, c2, c2p, hist);
+    vb_butterfly<J0 + 8>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 9>(P, N, c2, c2p, hist);  vb_butterfly<J0 + 10>(P, N, c2, c2p, hist); vb_butterfly<J0 + 11>(P, N, c2, c2p, hist);
+    vb_butterfly<J0 + 12>(P, N, c2, c2p, hist); vb_butterfly<J0 + 13>(P, N, c2, c2p, hist); vb_butterfly<J0 + 14>(P, N, c2, c2p, hist); vb_butterfly<J0 + 15>(P, N, c2, c2p, hist);
+}
+
+// puncturing rows (A, B) of the K = 7 codes as bit masks over the column
+__device__ __forceinline__ void vb_punct(int p, unsigned &pa, unsigned &pb)
+{
+    switch (p) {
+    case 2: pa = 0x3; pb = 0x1; break;   case 3: pa = 0x3; pb = 0x5; break;   case 4: pa = 0xf; pb = 0x1; break;
+    case 5: pa = 0xb; pb = 0x15; break;  case 6: pa = 0x17; pb = 0x29; break; case 7: pa = 0x2f; pb = 0x51; break;
+    default: pa = 0x1; pb = 0x1; break;
+    }
+}
+
+// One trellis step of one lane: P -> N.  Returns the 64 decision bits.
+__device__ __forceinline__ unsigned long long vb_step(const uint32_t (&P)[64], uint32_t (&N)[64], unsigned pa, unsigned pb, unsigned up, uint32_t &col, uint32_t &nb,
+                                                      uint32_t w0, uint32_t w1, uint32_t wbase, bool adv)
+{
+    const unsigned hasA = (pa >> col) & 1u, hasB = (pb >> col) & 1u;
+    const unsigned long long w64 = ((unsigned long long)w0 << 32) | w1;
+    const unsigned top2 = (unsigned)((w64 << ((nb - wbase) & 63u)) >> 62);
+    const unsigned ra = top2 >> 1, rb = hasA ? (top2 & 1u) : (top2 >> 1);
+    // 2 x cost of the expected pair e = A | B << 1 against what was received (punctured positions cost nothing)
+    const uint32_t a0 = (hasA & ra) << 1, a1 = (hasA & (ra ^ 1u)) << 1, b0 = (hasB & rb) << 1, b1 = (hasB & (rb ^ 1u)) << 1;
+    const uint32_t c2[4] = { a0 + b0, a1 + b0, a0 + b1, a1 + b1 };
+    const uint32_t c2p[4] = { c2[0] | 1u, c2[1] | 1u, c2[2] | 1u, c2[3] | 1u };
+    uint32_t h0 = 0, h1 = 0;
+    vb_half<0>(P, N, c2, c2p, h0);
+    vb_half<16>(P, N, c2, c2p, h1);
+    if (adv) { nb += hasA + hasB; col = col + 1u == up ? 0u : col + 1u; }
+    return ((unsigned long long)h1 << 32) | h0;
+}
+
+// The forward pass of one lane over a stretch of the trellis of a frame (coded bits at enc: packed, MSB first, punctured
+// with period p).  The loop is the wave's: nsteps iterations (even), the lane's region [t_reg, t1) starting at iteration
+// reg_at; before that a lane either warms up (init 0: all-equal metrics at t_reg - reg_at) or idles (init 1: the encoder's
+// start state, init 2: metric differences read from init_vec).  Decisions of region steps go to dw[t].
+__device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t_reg, uint32_t t1, int init, const uint8_t *init_vec,
+                                           unsigned long long *dw, uint8_t *start_vec, uint8_t *end_vec, uint32_t nsteps, uint32_t reg_at, bool lane_on)
+{
+    uint32_t P[64], N[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) P[i] = 0u;
+    unsigned pa, pb; vb_punct(p, pa, pb);
+    const unsigned up = (unsigned)p;
+    const uint32_t ts = init == 0 ? t_reg - reg_at : t_reg;               // first step this lane really runs
+    uint32_t col = ts % up;
+    uint32_t nb = (p == 1) ? 2u * ts : ts + (ts + up - 1u) / up;          // coded bits before step ts
+    const uint32_t *enc32 = reinterpret_cast<const uint32_t *>(enc);      // (byte_off is a multiple of 16)
+    uint32_t w0 = 0, w1 = 0, wbase = 0;
+    for (uint32_t u = 0; u < nsteps; u += 2) {
+        if (u == reg_at) {
+            if (init == 1) {
+#pragma unroll
+                for (int i = 1; i < 64; i++) P[i] = 1u << 24;
+                P[0] = 0u;
+            } else if (init == 2) {
+#pragma unroll
+                for (int i = 0; i < 64; i++) P[i] = init_vec[i];
+            } else if (lane_on && start_vec) vb_save_vec(P, start_vec);
+        }
+        if ((u & 15u) == 0u) {                                             // refill the 64-bit window of coded bits
+            const uint32_t idx = nb >> 5;
+            const uint32_t x0 = lane_on ? enc32[idx] : 0u, x1 = lane_on ? enc32[idx + 1] : 0u;
+            w0 = __builtin_bswap32(x0); w1 = __builtin_bswap32(x1); wbase = idx << 5;
+        }
+        const bool run = u >= reg_at || init == 0;                          // (a lane that idles keeps its stream position)
+        const unsigned long long d0 = vb_step(P, N, pa, pb, up, col, nb, w0, w1, wbase, run);
+        const unsigned long long d1 = vb_step(N, P, pa, pb, up, col, nb, w0, w1, wbase, run);
+        // (regions start at multiples of 64 steps: dw[t], dw[t+1] is an aligned 16-byte pair; the arena has slack behind t1)
+        const uint32_t t = t_reg - reg_at + u;
+        if (lane_on && u >= reg_at && t < t1) *reinterpret_cast<ulonglong2 *>(dw + t) = make_ulonglong2(d0, d1);
+    }
+    if (lane_on && end_vec) vb_save_vec(P, end_vec);
+}
+
+// ---- forward pass: one lane per (frame, trellis block) work item; the items of a wave share their puncturing code ----
+// vb_items: [0, cap) the frame of every item slot (0xFFFFFFFF: padding of a code class's last wave), [cap, 2 cap) its block
+extern "C" __global__ __launch_bounds__(64)
+void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
+                     unsigned long long *dw_arena, uint8_t *vec_arena)
+{
+    const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
+    const uint32_t it0 = first_item + blockIdx.x * 64u;
+    if (it0 >= nitems) return;
+    const uint32_t item = vb_items[it0 + threadIdx.x], b = vb_items[item_cap + it0 + threadIdx.x];
+    const bool lane_on = item != 0xFFFFFFFFu;
+    const unsigned long long live = __ballot(lane_on);
+    if (!live) return;
+    const uint32_t g = lane_on ? item : 0u;
+    const FxPayJob &job = jobs[g];
+    // (a padding slot has no frame of its own: the wave's code class is read from a live lane)
+    const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)live) - 1, 64));
+    const uint32_t Tn = 8u * job.k + 6u;
+    const uint32_t t_reg = (lane_on ? b : 0u) * blk, t1 = min(Tn, t_reg + blk);
+    uint8_t *vec = vec_arena + (size_t)(job.vb_off + (lane_on ? b : 0u)) * 128u;
+    const bool first = !lane_on || b == 0;
+    vb_forward(bufB + job.byte_off, p, first ? 0u : t_reg, t1, first ? 1 : 0, nullptr, dw_arena + job.dw_off, first ? nullptr : vec, vec + 64,
+               FX_VB_WARM + blk, FX_VB_WARM, lane_on);
+}
+
+extern "C" hipError_t fx_launch_vbfwd(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
+                                      const FxBlockHdr *hdr, const uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena)
+{
+    if (n_items == 0) return hipSuccess;
+    hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 63) / 64), dim3(64), 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dw_arena, vec_arena);
+    return hipGetLastError();
+}
+
+// ---- front part, one wave per frame: symbols -> packet bytes, de-interleave, fec1 (not convolutional), de-interleave ----
+extern "C" __global__ __launch_bounds__(DEC_THREADS)
+void fx_vbpre_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB,
+                     const FxTables *T)
+{
+    const uint32_t njobs = hdr->n_dec_batch;
+    const uint32_t ji = first_wave + blockIdx.x;
+    if (ji >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t jf = job_idx[ji];
+    FxPayJob job = jobs[jf];
+    job.l0 = __builtin_amdgcn_readfirstlane(job.l0); job.l1 = __builtin_amdgcn_readfirstlane(job.l1);
+    job.fec1 = __builtin_amdgcn_readfirstlane(job.fec1); job.bps = __builtin_amdgcn_readfirstlane(job.bps);
+    uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
+    const uint8_t *hs = hard + job.sym_off;
+    const unsigned bps = job.bps;
+    for (uint32_t j = lane; j < job.l1; j += DEC_THREADS) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t k = 8 * j + b, sidx = k / bps, sb = bps - 1 - (k % bps);
+            v = (v << 1) | ((hs[sidx] >> sb) & 1u);
+        }
+        A[j] = (uint8_t)v;
+    }
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    deinterleave_wave(A, job.l1, lane);
+    block_fec_decode<false>(job.fec1, job.l0, A, B, T, lane);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    deinterleave_wave(B, job.l0, lane);
+    // (the window reads of the forward pass run up to 8 bytes past the coded bits: keep them defined)
+    if (lane < 8) B[job.l0 + lane] = 0;
+}
+
+// ---- back part, one wave per frame: verify the blocks' hand-overs (repair where they do not hold), trace back, finish ----
+__device__ __forceinline__ void vb_traceback(const unsigned long long *dw, uint32_t Tn, uint8_t *dec, uint8_t *scratch, int lane)
+{
+    // Parallel over 64-step chunks with exact verification, as in viterbi27: chunk c is first entered from a guess of its end
+    // state (chunk c+1 traced back from state 0), then the chain of chunk start states is checked and chunks entered from a
+    // wrong state are traced again, to the fixed point.  Decision words are one per step here, so their addresses do not
+    // depend on the state: a lane streams its chunk's 64 words.
+    const uint32_t nchunk = (Tn + 63) / 64, Lc = nchunk - 1;
+    uint8_t *Sarr = scratch, *Barr = scratch + nchunk;
+    // (the decision words' addresses do not depend on the state: sixteen of them are fetched at a time, 16-byte loads, and
+    // then walked through from registers -- four memory round trips per chunk instead of sixty-four; the arena has slack
+    // behind the last step, so whole groups are read)
+    auto trace = [&](uint32_t c, unsigned st, uint32_t (&bits)[2]) -> unsigned {
+        const uint32_t t0 = 64u * c, ns = min(64u, Tn - t0);
+        bits[0] = bits[1] = 0u;
+#pragma unroll
+        for (int grp = 3; grp >= 0; grp--) {
+            if ((uint32_t)(16 * grp) >= ns) continue;
+            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(dw + t0 + 16u * (uint32_t)grp);
+            ulonglong2 q[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) q[i] = src[i];
+#pragma unroll
+            for (int i = 15; i >= 0; i--) {
+                const int u = 16 * grp + i;
+                if ((uint32_t)u < ns) {
+                    const unsigned long long w = (i & 1) ? q[i >> 1].y : q[i >> 1].x;
+                    bits[u >> 5] |= (st & 1u) << (u & 31);
+                    st = (st >> 1) | ((unsigned)((w >> st) & 1ull) << 5);
+                }
+            }
+        }
+        return st;
+    };
+    auto emit = [&](uint32_t c, const uint32_t (&b)[2]) {
+        uint32_t lo = 0, hi = 0;                                          // steps 64c .. 64c+63 are output bytes 8c .. 8c+7, MSB first
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            lo |= (__brev((b[0] >> (8 * k)) & 0xffu) >> 24) << (8 * k);
+            hi |= (__brev((b[1] >> (8 * k)) & 0xffu) >> 24) << (8 * k);
+        }
+        *reinterpret_cast<uint2 *>(dec + 8 * (size_t)c) = make_uint2(lo, hi);
+    };
+    for (uint32_t base = 0; base < nchunk; base += 64) {
+        const uint32_t c = base + lane;
+        if (c < nchunk) {
+            uint32_t bits[2]; unsigned S = 0;
+            if (c < Lc) S = trace(c + 1, 0u, bits);                        // warm-up through chunk c+1 from state 0
+            const unsigned Bst = trace(c, S, bits);
+            Sarr[c] = (uint8_t)S; Barr[c] = (uint8_t)Bst; emit(c, bits);
+        }
+    }
+    for (;;) {
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+        bool changed = false;
+        for (uint32_t base = 0; base < nchunk; base += 64) {
+            const uint32_t c = base + lane;
+            bool redo = false; unsigned need = 0;
+            if (c < nchunk) { need = c == Lc ? 0u : Barr[c + 1]; redo = Sarr[c] != need; }
+            if (redo) {
+                uint32_t bits[2];
+                const unsigned Bst = trace(c, need, bits);
+                Sarr[c] = (uint8_t)need; Barr[c] = (uint8_t)Bst; emit(c, bits);
+            }
+            if (__any(redo)) changed = true;
+        }
+        if (!changed) break;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64)
+void fx_vbpost_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, uint8_t *bufA, uint8_t *bufB,
+                      unsigned long long *dw_arena, uint8_t *vec_arena, uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_stats)
+{
+    const uint32_t njobs = hdr->n_dec_batch, blk = hdr->vb_blk;
+    const uint32_t ji = first_wave + blockIdx.x;
+    if (ji >= njobs) return;
+    const int lane = threadIdx.x & 63;
+    const uint32_t jf = job_idx[ji];
+    FxPayJob job = jobs[jf];
+    job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
+    job.check = __builtin_amdgcn_readfirstlane(job.check); job.vb_nblk = __builtin_amdgcn_readfirstlane(job.vb_nblk);
+    uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
+    unsigned long long *dw = dw_arena + job.dw_off;
+    uint8_t *vecs = vec_arena + (size_t)job.vb_off * 128u;
+    const uint32_t Tn = 8u * job.k + 6u;
+    const int p = conv_p(job.fec0);
+    // 1. every block's start differences must be the end differences of the block before it; where they are not, the block is
+    //    run again from the true ones (every lane does the same work on the same data: one lane's worth, no exchange needed)
+    uint32_t repaired = 0;                                                   // blocks run again (reported in the frame's status word)
+    for (uint32_t b = 1; b < job.vb_nblk; b++) {
+        const uint8_t *endp = vecs + (size_t)(b - 1) * 128u + 64, *startp = vecs + (size_t)b * 128u;
+        const bool same = endp[lane] == startp[lane];
+        if (__all(same)) continue;
+        const uint32_t t_reg = b * blk, t1 = min(Tn, t_reg + blk);
+        vb_forward(B, p, t_reg, t1, 2, endp, dw, nullptr, vecs + (size_t)b * 128u + 64, blk, 0u, true);
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+        repaired++;
+    }
+    // 2. trace back into A (k bytes), 3. de-whiten, CRC, payload out
+    vb_traceback(dw, Tn, A, B, lane);
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    dec_tail(job, jf, A, lane, out, recs, repaired << 8);
+}
+
+extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
+                                      const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, const FxTables *T)
+{
+    if (n_waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(fx_vbpre_kernel, dim3(n_waves), dim3(DEC_THREADS), 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, T);
+    return hipGetLastError();
+}
+extern "C" hipError_t fx_launch_vbpost(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
+                                       uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena, uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_stats)
+{
+    if (n_waves == 0) return hipSuccess;
+    hipLaunchKernelGGL(fx_vbpost_kernel, dim3(n_waves), dim3(64), 0, st, jobs, job_idx, hdr, first_wave, bufA, bufB, dw_arena, vec_arena, out, recs, hdr_stats);
     return hipGetLastError();
 }
 

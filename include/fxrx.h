@@ -207,7 +207,9 @@ typedef struct {
     double   host_collectwait_ms;                /* wall time fxrx_collect waited for the block's results */
     uint64_t walk_mode;                          /* 0: all streams started freshly reset, 1: some continued the previous block (true walkers ordered behind its chain kernel) */
     double   chain_ms;                           /* fx_chain_kernel + fx_plan_kernel */
-    uint64_t replays;                            /* carry-buffer overflows handled so far (blocks behind the overflowing one were enqueued again) */
+    uint64_t replays;                            /* carry-buffer overflows / chain repairs handled so far (blocks behind were enqueued again) */
+    uint64_t vb_blocks, vb_repairs;              /* batch Viterbi: trellis blocks (incl. padding slots) / blocks run again because a hand-over check failed */
+    uint64_t late_decodes;                       /* blocks whose decode launches had to be completed at collect (more frames than the grids were sized for) */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
 /* the HIP stream (hipStream_t as void*) of the first slot of the ring of blocks in flight; every block runs its whole kernel

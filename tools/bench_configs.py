@@ -48,15 +48,21 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
     # the same passes with several in flight (each pass is an independent capture of all streams: reset in between)
     depth = 4
     ctx.set_depth(depth)
+    acc = {}
+    def collect():
+        ctx.collect_raw()
+        t = ctx.timing()
+        for k in ("late_decodes", "replays", "vb_repairs", "vb_blocks", "total_ms", "paydec_ms", "walk_ms", "chain_ms"):
+            acc[k] = acc.get(k, 0) + t[k]
     def pipelined(k):
         infl = 0
         for _ in range(k):
             if infl == depth:
-                ctx.collect_raw(); infl -= 1
+                collect(); infl -= 1
             ctx.reset(); ctx.submit_raw(ptrs, counts, True); infl += 1
         while infl:
-            ctx.collect_raw(); infl -= 1
-    pipelined(depth)
+            collect(); infl -= 1
+    pipelined(depth); acc.clear()
     torch.cuda.synchronize(); t0 = time.perf_counter()
     pipelined(3 * passes)
     torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / (3 * passes)
@@ -65,6 +71,7 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
                ms_per_pass=round(dt * 1e3, 3), msamples_per_s=round(n_streams * n_samples / dt / 1e6, 1),
                ms_per_pass_4_in_flight=round(dtp * 1e3, 3), msamples_per_s_4_in_flight=round(n_streams * n_samples / dtp / 1e6, 1),
                kernels_ms={k: round(tm[k], 3) for k in ("walk_ms", "seekverify_ms", "chain_ms", "paymf_ms", "paypll_ms", "paydec_ms")},
+               in_flight_sums={k: round(v, 3) for k, v in acc.items()},
                hops=tm["hops"], hops_cheap=tm["hops_cheap"], walk_jobs=tm["walk_jobs"], repairs=tm["repairs"])
     print(json.dumps(out), flush=True)
     ctx.close()
