@@ -62,7 +62,7 @@ class Timing(C.Structure):                  # fxrx_timing
                 ("frames", C.c_uint64), ("payload_symbols", C.c_uint64), ("samples", C.c_uint64), ("hops_cheap", C.c_uint64),
                 ("host_submit_ms", C.c_double), ("host_walkwait_ms", C.c_double),
                 ("seekverify_ms", C.c_double), ("verify_hops", C.c_uint64), ("verify_failures", C.c_uint64),
-                ("host_collectwait_ms", C.c_double), ("walk_mode", C.c_uint64), ("chain_ms", C.c_double), ("replays", C.c_uint64), ("vb_blocks", C.c_uint64), ("vb_repairs", C.c_uint64), ("late_decodes", C.c_uint64)]
+                ("host_collectwait_ms", C.c_double), ("walk_mode", C.c_uint64), ("chain_ms", C.c_double), ("replays", C.c_uint64), ("vb_blocks", C.c_uint64), ("vb_repairs", C.c_uint64), ("late_decodes", C.c_uint64), ("vb_fallbacks", C.c_uint64)]
 
 
 # every symbol include/fxrx.h declares (checked by tests/test_cabi.py)

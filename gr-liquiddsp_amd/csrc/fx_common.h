@@ -185,6 +185,8 @@ struct FxBlockHdr {                      // device memory, zeroed at submit; mir
     uint32_t flags;
     uint32_t n_frames, n_pjobs, n_mfblk, n_dec_plain, n_dec_rs, n_dec_batch;   // n_dec_batch: frames decoded by the batch Viterbi path
     uint32_t n_vb_items, vb_blk;         // its forward-pass work items (frame, trellis block) / trellis steps per block
+    uint32_t vb_want;                    // work items the block's traffic asked for (those beyond the arena go the wave-per-frame way)
+    uint32_t n_vb_fallback;              // frames the batch path could not verify: decoded again by the wave-per-frame decoder
     uint32_t pll_cnt[FX_PLL_CLASSES];    // frames per modulation class
     uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
     uint64_t sym_total, byte_total, dw_total, out_total;

@@ -54,17 +54,18 @@ extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams
                                      FxBlockHdr *hdr_host);
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
                                       const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, const FxTables *T);
-extern "C" hipError_t fx_launch_vbfwd(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
-                                      const FxBlockHdr *hdr, const uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena);
-extern "C" hipError_t fx_launch_vbpost(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
-                                       uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena, uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_stats);
+extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
+                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg);
+extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
+                                         uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
+                                         uint8_t *out, FxOutRec *recs);
 extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                       const FxFrame *chain, float2 *sym_raw, const FxTables *T);
 extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
                                        const float2 *sym_raw, float2 *framesyms, uint8_t *hard, FxOutRec *recs, const FxTables *T);
 extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
                                        const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, uint8_t *soft_arena,
-                                       unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T);
+                                       unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T, FxBlockHdr *fallback_host);
 extern "C" hipError_t fx_launch_softdemod(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                           const float2 *framesyms, const uint8_t *hard, uint8_t *soft_arena, const FxTables *T);
 
@@ -112,6 +113,7 @@ template <class T> struct PinBuf {
 
 constexpr unsigned kMaxDepth = 16;
 constexpr unsigned kStateRing = kMaxDepth + 3;      // FxStreamState records per stream: one per block in flight and then some
+constexpr uint32_t kFallbackWaves = 32;             // in-chain launch for frames the batch Viterbi path hands back (normally none)
 constexpr uint32_t kRepairCap = 256;                // frame-table slots per stream for walks done by the chain kernel
 
 struct StreamState {
@@ -147,7 +149,9 @@ struct Slot {
     DevBuf<FxBlockHdr> d_hdr;                // [0] walk-phase counters (zero between blocks), [1] what the payload kernels read
     DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list, d_vb_items;
     DevBuf<uint8_t> d_vb_vec;                // batch Viterbi: metric differences at the start and end of every trellis block
-    uint32_t vb_cap = 0, vb_blk = 0, vb_pre_launched = 0, vb_items_launched = 0;
+    DevBuf<unsigned long long> d_vb_dw;      // its decision words, step-major within the 64 work items of a wave
+    DevBuf<uint32_t> d_vb_st;                // traceback states and flags per work item
+    uint32_t vb_cap = 0, vb_blk = 0, vb_pre_launched = 0, vb_items_launched = 0, fb_launched = 0;
     DevBuf<FxPayJob> d_pjobs; DevBuf<FxPayResult> d_pres;
     uint32_t run_cap = 0, chain_cap = 0, mf_cap = 0, frame_slots = 0;
     uint64_t sym_cap = 0, byte_cap = 0, dw_cap = 0, out_cap = 0;
@@ -179,9 +183,10 @@ struct fxrx_ctx_s {
     hipEvent_t carry_reader[3] = { nullptr, nullptr, nullptr };   // payload MF of the newest block that reads carry[i]
     uint32_t verify_per = 4;             // hops per verification run (adapted to the traffic)
     uint64_t frames_hint = 0, rs_hint = 0;   // frames / Reed-Solomon frames of the last collected block (size the PLL / decode grids)
-    uint64_t plain_hint = 0, batch_hint = 0, vb_items_hint = 0, vb_steps_hint = 0;   // likewise: frames of the wave-per-frame / batch decoders, trellis blocks, trellis steps
+    uint64_t plain_hint = 0, batch_hint = 0, vb_items_hint = 0, vb_steps_hint = 0, vb_want_hint = 0;   // likewise: frames of the wave-per-frame / batch decoders, trellis blocks, trellis steps
     bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
+    uint32_t vb_debug = 0, vb_blk_force = 0;   // tests: FXRX_VB_DEBUG (see fx_vbfix_kernel / fx_vbtrace_kernel), FXRX_VB_BLK (trellis steps per block)
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
     Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
@@ -310,6 +315,9 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_VB_DEBUG")) c->vb_debug = (uint32_t)std::atoi(e);
+    // (a block is at least as long as the warm-up of the next one: 128 steps)
+    if (const char *e = std::getenv("FXRX_VB_BLK")) if (std::atoi(e) > 0) c->vb_blk_force = (uint32_t)std::min(4096, std::max(128, (std::atoi(e) + 63) / 64 * 64));
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess) c->n_cus = prop.multiProcessorCount;
     if (upload_tables(c) != 0) return fail();
@@ -435,10 +443,18 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     sl.dw_cap = detect ? 0 : (span / 2) * 6 + 200ull * chain_slots + 64;
     sl.out_cap = (span / 2) * 3 / 4 + 16ull * chain_slots + 64;
     sl.mf_cap = (uint32_t)std::min<uint64_t>(span / 2 / 1024 + chain_slots + 16, 0x7fffffffu);
-    // batch Viterbi: trellis steps per block from the traffic of the last block (enough blocks to fill the chip, few enough to
-    // keep the warm-up cheap); its work items number at most (coded bits) / blk + one per frame + padding per code class
-    sl.vb_blk = (detect || c->cfg.soft_decision || !c->batch_viterbi) ? 0u : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(c->depth > 1 ? 512 : 192, ((c->vb_steps_hint / 65536 + 63) / 64) * 64));
-    sl.vb_cap = sl.vb_blk ? (uint32_t)std::min<uint64_t>(3 * span / sl.vb_blk + chain_slots + 512, 0x7fffffffu) : 1u;
+    // batch Viterbi: trellis steps per block from the traffic of the last block.  The forward pass is arithmetic bound, three
+    // waves to a SIMD: some six waves per SIMD spread evenly over the chip, fewer and the slowest SIMD sets the time; blocks
+    // shorter than a few warm-ups waste their work (with several blocks in flight the chip is full anyway: longer blocks).
+    {
+        const uint64_t want_items = 64ull * 4ull * (uint64_t)c->n_cus * 6ull;
+        sl.vb_blk = (detect || c->cfg.soft_decision || !c->batch_viterbi) ? 0u
+                  : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(c->depth > 1 ? 512 : 192, ((c->vb_steps_hint / want_items + 63) / 64) * 64));
+    }
+    if (sl.vb_blk && c->vb_blk_force) sl.vb_blk = c->vb_blk_force;
+    // (arena: what the last block's traffic asked for plus a margin, at least a sample's worth of steps per sample; frames
+    // whose work items do not fit are decoded by the wave-per-frame kernel, and the next block's arena is larger)
+    sl.vb_cap = sl.vb_blk ? (uint32_t)((std::min<uint64_t>(std::max<uint64_t>(span / sl.vb_blk, c->vb_want_hint + c->vb_want_hint / 4) + 1024, 4 * span / sl.vb_blk + 1024) + 63) & ~63ull) : 64u;
     if (sl.sym_cap >= (1ull << 32) || sl.dw_cap >= (1ull << 32)) { set_err("fxrx_submit: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
 
     // ---- 2. memory ----
@@ -449,11 +465,12 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (sl.hp_desc.reserve(desc_bytes) || sl.d_desc.reserve(desc_bytes) || sl.d_wres.reserve(NJ + NS) || sl.d_frames.reserve(frame_slots) ||
         sl.d_runs.reserve(sl.run_cap) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
-        sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(3 * (size_t)list_cap)) return FXRX_ERR_HIP;
+        sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(4 * (size_t)list_cap)) return FXRX_ERR_HIP;
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_framesyms.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
                     sl.d_bufA.reserve(sl.byte_cap) || sl.d_bufB.reserve(sl.byte_cap) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.want_framesyms && sl.h_framesyms.reserve(sl.sym_cap)) return FXRX_ERR_HIP;
-    if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_cap) || (sl.vb_blk && sl.d_vb_vec.reserve(128 * (size_t)sl.vb_cap))) return FXRX_ERR_HIP;
+    if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_cap) ||
+        (sl.vb_blk && (sl.d_vb_vec.reserve(128 * (size_t)sl.vb_cap) || sl.d_vb_dw.reserve((size_t)sl.vb_cap * sl.vb_blk) || sl.d_vb_st.reserve(sl.vb_cap)))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.soft_decision && (sl.d_soft.reserve(8 * sl.byte_cap) || (c->cfg.want_framesyms && sl.h_soft.reserve(8 * sl.byte_cap)))) return FXRX_ERR_HIP;
 #ifdef FX_STAMPS
     if (!detect && sl.d_pres.reserve(chain_slots)) return FXRX_ERR_HIP;
@@ -541,18 +558,23 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
         sl.dec_launched = c->first_block ? chain_slots : (unsigned)std::min<uint64_t>(chain_slots, c->plain_hint + c->plain_hint / 2 + 64);
         sl.rs_launched = c->rs_hint ? (unsigned)std::min<uint64_t>(chain_slots, c->rs_hint + c->rs_hint / 2 + 64) : 0u;
         HIP_OK(fx_launch_paydec(0, soft, 0, sl.dec_launched, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p,
-                                sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+                                sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, nullptr));
         HIP_OK(fx_launch_paydec(1, soft, 0, sl.rs_launched, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p,
-                                sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+                                sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, nullptr));
         // batch Viterbi path (most frames: hard decisions, convolutional fec0): front part, forward pass over trellis blocks, back part
         if (sl.vb_blk) {
             sl.vb_pre_launched = c->first_block ? chain_slots : (unsigned)std::min<uint64_t>(chain_slots, c->batch_hint + c->batch_hint / 2 + 64);
             sl.vb_items_launched = c->first_block ? sl.vb_cap : (unsigned)std::min<uint64_t>(sl.vb_cap, c->vb_items_hint + c->vb_items_hint / 2 + 1024);
             HIP_OK(fx_launch_vbpre(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
-            HIP_OK(fx_launch_vbfwd(0, sl.vb_items_launched, st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufB.p, sl.d_dw.p, sl.d_vb_vec.p));
-            HIP_OK(fx_launch_vbpost(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p,
-                                    sl.d_vb_vec.p, sl.h_out.p, sl.h_recs.p, hdr_pay));
-        } else sl.vb_pre_launched = sl.vb_items_launched = 0;
+            HIP_OK(fx_launch_vbitems(0, sl.vb_items_launched, st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p,
+                                     sl.d_vb_st.p, c->vb_debug));
+            HIP_OK(fx_launch_vbfinish(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
+                                      sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p));
+            // frames whose hand-overs could not be verified (a repair behind a repair): the wave-per-frame decoder, a few waves
+            sl.fb_launched = kFallbackWaves;
+            HIP_OK(fx_launch_paydec(0, 0, 0, sl.fb_launched, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
+                                    sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
+        } else sl.vb_pre_launched = sl.vb_items_launched = sl.fb_launched = 0;
         HIP_OK(hipEventRecord(sl.ev[7], st));
         // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
         if (c->cfg.want_framesyms)
@@ -678,7 +700,8 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
     const FxBlockHdr &h = *sl.h_hdr.p;
     const bool more_plain = h.n_dec_plain > sl.dec_launched, more_rs = h.n_dec_rs > 0 && sl.rs_launched == 0;   // (the Reed-Solomon instance strides: any launch covers all)
     const bool more_batch = h.n_dec_batch > sl.vb_pre_launched || h.n_vb_items > sl.vb_items_launched;
-    if (!more_plain && !more_rs && !more_batch) return 0;
+    const bool more_fb = sl.vb_blk && h.n_vb_fallback > sl.fb_launched;
+    if (!more_plain && !more_rs && !more_batch && !more_fb) return 0;
     const uint32_t list_cap = sl.chain_cap + 64 * FX_PLL_CLASSES;
     FxBlockHdr *hdr_pay = sl.d_hdr.p + 1;
     const int soft = c->cfg.soft_decision ? 1 : 0;
@@ -688,16 +711,26 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
 #endif
     if (more_plain)
         HIP_OK(fx_launch_paydec(0, soft, sl.dec_launched, h.n_dec_plain - sl.dec_launched, c->dec_waves, sl.st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p,
-                                sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
+                                sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, nullptr));
     if (more_rs)
         HIP_OK(fx_launch_paydec(1, soft, 0, h.n_dec_rs, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
-                                sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables));
-    if (more_batch) {       // (all three parts again, for all of the path's frames: they are idempotent)
+                                sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, nullptr));
+    if (more_batch) {       // (all parts again, for all of the path's frames: they are idempotent -- but for the fallback list, which starts over)
+        HIP_OK(hipMemsetAsync(&hdr_pay->n_vb_fallback, 0, sizeof(uint32_t), sl.st));
         HIP_OK(fx_launch_vbpre(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
-        HIP_OK(fx_launch_vbfwd(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufB.p, sl.d_dw.p, sl.d_vb_vec.p));
-        HIP_OK(fx_launch_vbpost(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_dw.p, sl.d_vb_vec.p,
-                                sl.h_out.p, sl.h_recs.p, hdr_pay));
-        sl.vb_pre_launched = h.n_dec_batch; sl.vb_items_launched = h.n_vb_items;
+        HIP_OK(fx_launch_vbitems(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p, sl.d_vb_st.p, c->vb_debug));
+        HIP_OK(fx_launch_vbfinish(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
+                                  sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p));
+        HIP_OK(fx_launch_paydec(0, 0, 0, kFallbackWaves, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
+                                sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
+        sl.vb_pre_launched = h.n_dec_batch; sl.vb_items_launched = h.n_vb_items; sl.fb_launched = kFallbackWaves;
+        HIP_OK(hipStreamSynchronize(sl.st));
+    }
+    const uint32_t n_fb = *(volatile const uint32_t *)&sl.h_hdr.p->n_vb_fallback;
+    if (sl.vb_blk && n_fb > sl.fb_launched) {
+        HIP_OK(fx_launch_paydec(0, 0, sl.fb_launched, n_fb - sl.fb_launched, c->dec_waves, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay,
+                                sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
+        sl.fb_launched = n_fb;
     }
     HIP_OK(hipStreamSynchronize(sl.st));
     sl.dec_launched = std::max(sl.dec_launched, h.n_dec_plain); if (more_rs) sl.rs_launched = h.n_dec_rs;
@@ -760,7 +793,7 @@ int fxrx_collect(fxrx_ctx *c)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
     c->frames_hint = h.n_frames; c->plain_hint = h.n_dec_plain; c->batch_hint = h.n_dec_batch; c->vb_items_hint = h.n_vb_items;
-    c->vb_steps_hint = (uint64_t)h.n_vb_items * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
+    c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
     c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - c->rs_hint / 8;      // (fades out over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
@@ -777,7 +810,7 @@ int fxrx_collect(fxrx_ctx *c)
     t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs; t.frames = h.n_frames;
     t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops + sl.kept_vhops; t.verify_failures = h.verify_failures + sl.kept_vfail;
     t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays + c->repairs_host;
-    t.vb_blocks = h.n_vb_items; t.vb_repairs = vb_rep; t.late_decodes = c->late_decodes;
+    t.vb_blocks = h.n_vb_items; t.vb_repairs = vb_rep; t.late_decodes = c->late_decodes; t.vb_fallbacks = h.n_vb_fallback;
     sl.busy = false; c->last = &sl;
     c->tail = (c->tail + 1) % nslots; c->inflight--;
     return (int)sl.out.size();

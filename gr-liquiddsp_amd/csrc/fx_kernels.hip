@@ -1315,8 +1315,10 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             }
         }
         plan_scan(v, tot, ws);
+        // (work items beyond the arena, padding of the seven code classes included: the frame goes the wave-per-frame way, and
+        // so does every frame behind it)
+        if (batch && (uint64_t)vb_run + v[6] + vnb + 7u * 64u > vb_cap) { batch = false; vnb = 0; }
         const uint32_t sym_off = sym_run + v[0], byte_off = byte_run + v[1], dw_off = dw_run + v[2], out_off = out_run + v[3], mf_off = mf_run + v[4];
-        const uint32_t vb_off = vb_run + v[6];
         sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; npj += tot[5]; vb_run += tot[6];
         if (live) {
             const FxStreamDesc &sd = streams[sidx];
@@ -1326,7 +1328,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             j.nsym = valid ? fp->pay_sym_len : 0u; j.sym_off = sym_off;
             j.pay_len = fp->pay_len; j.check = fp->check; j.fec0 = fp->fec0; j.fec1 = fp->fec1; j.k = k; j.l0 = l0; j.l1 = l1;
             j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = valid ? 1u : 0u;
-            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain); j.vb_off = vb_off; j.vb_nblk = vnb;
+            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain); j.vb_off = 0; j.vb_nblk = vnb;
             pjobs[g] = j;
             // the record goes to pinned host memory: assemble it in registers, send it as eight 16-byte stores
             union { FxOutRec r; uint4 q[sizeof(FxOutRec) / 16]; } u;
@@ -1381,6 +1383,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             const int vc = conv_p(j.fec0) - 1;
             const uint32_t at = vbc_base[vc] + atomicAdd(&vbc_fill[vc], j.vb_nblk);
             for (uint32_t b = 0; b < j.vb_nblk; b++) if (at + b < vb_cap) { vb_items[at + b] = g; vb_items[vb_cap + at + b] = b; }
+            pjobs[g].vb_off = at;
         }
     }
     __syncthreads();
@@ -1388,7 +1391,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     if (tid == 0) {
         FxBlockHdr h = *hdr;
         h.n_frames = N; h.n_pjobs = npj; h.n_mfblk = min(mf_run, mf_cap); h.n_dec_plain = dec_cnt[0]; h.n_dec_rs = dec_cnt[1];
-        h.n_dec_batch = dec_cnt[2]; h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk;
+        h.n_dec_batch = dec_cnt[2]; h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk; h.vb_want = vb_run + 7u * 64u; h.n_vb_fallback = 0;
         for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = cls_cnt[c]; h.pll_base[c] = cls_base[c]; }
         h.pll_base[FX_PLL_CLASSES] = cls_base[FX_PLL_CLASSES];
         h.sym_total = sym_run; h.byte_total = byte_run; h.dw_total = dw_run; h.out_total = out_run;
@@ -2289,12 +2292,16 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
 template <bool WITH_RS, bool SOFT>
 __global__ __launch_bounds__(WITH_RS ? DEC_THREADS : DEC_THREADS * DEC_MAX_WAVES)
 void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, const uint8_t *hard, uint8_t *bufA,
-                      uint8_t *bufB, uint8_t *soft_arena, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+                      uint8_t *bufB, uint8_t *soft_arena, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T,
+                      FxBlockHdr *fallback_host)
 {
     // The list's length is known on the device only.  The lean instance has no loop around its body (a grid-stride loop
     // doubles the register footprint): the host launches it over the list's capacity -- a grid sized from the previous block
     // plus a second, normally idle one for the rest -- and surplus waves leave at once.  The Reed-Solomon instance strides.
-    const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : hdr->n_dec_plain;
+    // (fallback_host set: the list is that of the frames the batch Viterbi path handed back, and its length is passed on to
+    // the host's copy of the header, for fxrx_collect to see whether this launch covered it)
+    const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : (fallback_host ? hdr->n_vb_fallback : hdr->n_dec_plain);
+    if (!WITH_RS && fallback_host && first_wave == 0 && blockIdx.x == 0 && threadIdx.x == 0) fallback_host->n_vb_fallback = njobs;
     const uint32_t wpg = blockDim.x >> 6;
     const int lane = threadIdx.x & 63;
     const uint32_t ji0 = __builtin_amdgcn_readfirstlane(first_wave + blockIdx.x * wpg + (threadIdx.x >> 6));
@@ -2309,12 +2316,12 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
 
 extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
                                        const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, uint8_t *soft_arena,
-                                       unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T)
+                                       unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T, FxBlockHdr *fallback_host)
 {
     if (grid_waves == 0) return hipSuccess;
     const unsigned w = with_rs ? 1u : (waves_per_wg < 1u ? 1u : (waves_per_wg > DEC_MAX_WAVES ? DEC_MAX_WAVES : waves_per_wg));
     const dim3 grid((grid_waves + w - 1) / w), block(DEC_THREADS * w);
-#define FX_DEC_LAUNCH(RS, SF) hipLaunchKernelGGL((fx_paydec_kernel<RS, SF>), grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T)
+#define FX_DEC_LAUNCH(RS, SF) hipLaunchKernelGGL((fx_paydec_kernel<RS, SF>), grid, block, 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T, fallback_host)
     if (with_rs) { if (soft) FX_DEC_LAUNCH(true, true); else FX_DEC_LAUNCH(true, false); }
     else { if (soft) FX_DEC_LAUNCH(false, true); else FX_DEC_LAUNCH(false, false); }
 #undef FX_DEC_LAUNCH
@@ -2416,12 +2423,20 @@ __device__ __forceinline__ unsigned long long vb_step(const uint32_t (&P)[64], u
     return ((unsigned long long)h1 << 32) | h0;
 }
 
+// Decision words are kept step-major within the 64 work items of a forward-pass wave: item slot i = 64 w + l keeps the word
+// of its region step u at dwv[(w * blk + u) * 64 + l].  A wave's store of one step is then one contiguous 512-byte piece,
+// and the traceback wave (same items, same lanes, walking the steps downwards together) reads it back the same way.
+__device__ __forceinline__ unsigned long long *vb_slab(unsigned long long *dwv, uint32_t slot, uint32_t blk)
+{
+    return dwv + (size_t)(slot >> 6) * blk * 64u + (slot & 63u);
+}
+
 // The forward pass of one lane over a stretch of the trellis of a frame (coded bits at enc: packed, MSB first, punctured
 // with period p).  The loop is the wave's: nsteps iterations (even), the lane's region [t_reg, t1) starting at iteration
 // reg_at; before that a lane either warms up (init 0: all-equal metrics at t_reg - reg_at) or idles (init 1: the encoder's
-// start state, init 2: metric differences read from init_vec).  Decisions of region steps go to dw[t].
+// start state, init 2: metric differences read from init_vec).  Decisions of region step u go to dwl[64 u] (vb_slab).
 __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t_reg, uint32_t t1, int init, const uint8_t *init_vec,
-                                           unsigned long long *dw, uint8_t *start_vec, uint8_t *end_vec, uint32_t nsteps, uint32_t reg_at, bool lane_on)
+                                           unsigned long long *dwl, uint8_t *start_vec, uint8_t *end_vec, uint32_t nsteps, uint32_t reg_at, bool lane_on)
 {
     uint32_t P[64], N[64];
 #pragma unroll
@@ -2442,7 +2457,8 @@ __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t
             } else if (init == 2) {
 #pragma unroll
                 for (int i = 0; i < 64; i++) P[i] = init_vec[i];
-            } else if (lane_on && start_vec) vb_save_vec(P, start_vec);
+            }
+            if (init != 1 && lane_on && start_vec) vb_save_vec(P, start_vec);
         }
         if ((u & 15u) == 0u) {                                             // refill the 64-bit window of coded bits
             const uint32_t idx = nb >> 5;
@@ -2452,44 +2468,198 @@ __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t
         const bool run = u >= reg_at || init == 0;                          // (a lane that idles keeps its stream position)
         const unsigned long long d0 = vb_step(P, N, pa, pb, up, col, nb, w0, w1, wbase, run);
         const unsigned long long d1 = vb_step(N, P, pa, pb, up, col, nb, w0, w1, wbase, run);
-        // (regions start at multiples of 64 steps: dw[t], dw[t+1] is an aligned 16-byte pair; the arena has slack behind t1)
-        const uint32_t t = t_reg - reg_at + u;
-        if (lane_on && u >= reg_at && t < t1) *reinterpret_cast<ulonglong2 *>(dw + t) = make_ulonglong2(d0, d1);
+        // (regions are an even number of steps long within the slab: step ur + 1 is inside it whenever ur is)
+        const uint32_t ur = u - reg_at, t = t_reg + ur;
+        if (lane_on && u >= reg_at && t < t1) { dwl[(size_t)ur * 64u] = d0; dwl[(size_t)(ur + 1u) * 64u] = d1; }
     }
     if (lane_on && end_vec) vb_save_vec(P, end_vec);
 }
 
+// per work item, after the forward pass: [7:0] the end state its traceback started from, [15:8] the state it arrived at
+#define VB_ST_BAD 0x10000u        // the block's start differences are not the end differences of the block before it
+#define VB_ST_REP 0x20000u        // ... were not: the block has been run again from the true ones
+static_assert(FX_VB_WARM <= 128, "trellis blocks are at least 128 steps: a block's warm-up must fit into the block before it");
+#define FX_VB_TWARM 128           // traceback warm-up: steps of the next block traced from state 0 to guess the block's end state
+
 // ---- forward pass: one lane per (frame, trellis block) work item; the items of a wave share their puncturing code ----
 // vb_items: [0, cap) the frame of every item slot (0xFFFFFFFF: padding of a code class's last wave), [cap, 2 cap) its block
+struct VbItem { uint32_t g, b, t_reg, t1, Tn, nblk; bool on; };
+__device__ __forceinline__ VbItem vb_item(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, uint32_t slot, uint32_t blk)
+{
+    VbItem it;
+    const uint32_t item = vb_items[slot];
+    it.on = item != 0xFFFFFFFFu;
+    it.g = it.on ? item : 0u; it.b = it.on ? vb_items[item_cap + slot] : 0u;
+    const FxPayJob &job = jobs[it.g];
+    it.Tn = 8u * job.k + 6u; it.nblk = job.vb_nblk;
+    it.t_reg = it.b * blk; it.t1 = min(it.Tn, it.t_reg + blk);
+    return it;
+}
+
 extern "C" __global__ __launch_bounds__(64)
 void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
-                     unsigned long long *dw_arena, uint8_t *vec_arena)
+                     unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st)
 {
     const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
     const uint32_t it0 = first_item + blockIdx.x * 64u;
     if (it0 >= nitems) return;
-    const uint32_t item = vb_items[it0 + threadIdx.x], b = vb_items[item_cap + it0 + threadIdx.x];
-    const bool lane_on = item != 0xFFFFFFFFu;
-    const unsigned long long live = __ballot(lane_on);
+    const uint32_t slot = it0 + threadIdx.x;
+    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
+    const unsigned long long live = __ballot(it.on);
     if (!live) return;
-    const uint32_t g = lane_on ? item : 0u;
-    const FxPayJob &job = jobs[g];
+    const FxPayJob &job = jobs[it.g];
     // (a padding slot has no frame of its own: the wave's code class is read from a live lane)
     const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)live) - 1, 64));
-    const uint32_t Tn = 8u * job.k + 6u;
-    const uint32_t t_reg = (lane_on ? b : 0u) * blk, t1 = min(Tn, t_reg + blk);
-    uint8_t *vec = vec_arena + (size_t)(job.vb_off + (lane_on ? b : 0u)) * 128u;
-    const bool first = !lane_on || b == 0;
-    vb_forward(bufB + job.byte_off, p, first ? 0u : t_reg, t1, first ? 1 : 0, nullptr, dw_arena + job.dw_off, first ? nullptr : vec, vec + 64,
-               FX_VB_WARM + blk, FX_VB_WARM, lane_on);
+    uint8_t *vec = vec_arena + (size_t)slot * 128u;
+    const bool first = !it.on || it.b == 0;
+    vb_st[slot] = 0u;
+    vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, first ? 1 : 0, nullptr, vb_slab(dwv, slot, blk), first ? nullptr : vec, vec + 64,
+               FX_VB_WARM + blk, FX_VB_WARM, it.on);
 }
 
-extern "C" hipError_t fx_launch_vbfwd(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
-                                      const FxBlockHdr *hdr, const uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena)
+__device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
 {
-    if (n_items == 0) return hipSuccess;
-    hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 63) / 64), dim3(64), 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dw_arena, vec_arena);
-    return hipGetLastError();
+    const uint4 *pa = reinterpret_cast<const uint4 *>(a), *pb = reinterpret_cast<const uint4 *>(b);
+    bool same = true;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const uint4 x = pa[i], y = pb[i]; same = same && x.x == y.x && x.y == y.y && x.z == y.z && x.w == y.w; }
+    return same;
+}
+
+// ---- hand-over check: a block whose warm-up did not arrive at the true metric differences runs again from them ----
+// (same lanes as the forward pass; a wave without such a block leaves at once.  Should the block before it be run again as
+// well and end differently -- a repair behind a repair -- the check in fx_vbtrace_kernel still fails and the frame goes to
+// the wave-per-frame decoder: results never rest on an unverified hand-over.)
+extern "C" __global__ __launch_bounds__(64)
+void fx_vbfix_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
+                     unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+{
+    const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
+    const uint32_t it0 = first_item + blockIdx.x * 64u;
+    if (it0 >= nitems) return;
+    const uint32_t slot = it0 + threadIdx.x;
+    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
+    uint8_t *vec = vec_arena + (size_t)slot * 128u;
+    // (dbg bit 1, tests only: every other failing block is left as it is, for the fallback path to be exercised)
+    const bool bad = it.on && it.b > 0 && !vb_same64(vec, vec - 64) && !((dbg & 2u) && (slot & 1u));
+    const unsigned long long fails = __ballot(bad);
+    if (!fails) return;
+    const FxPayJob &job = jobs[it.g];
+    const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)fails) - 1, 64));
+    vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, 2, bad ? vec - 64 : vec, vb_slab(dwv, slot, blk), vec, vec + 64, blk, 0u, bad);
+    if (bad) vb_st[slot] = VB_ST_REP;                                       // (fx_vbfinish_kernel counts these)
+}
+
+// sixteen traceback steps u0 + 15 .. u0 of one lane (those below lim only): the words first, then the chain through them
+__device__ __forceinline__ void vb_trace16(const unsigned long long *dwl, uint32_t u0, uint32_t lim, unsigned &st, uint32_t &bits16)
+{
+    unsigned long long q[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) q[i] = (u0 + (uint32_t)i < lim) ? dwl[(size_t)(u0 + (uint32_t)i) * 64u] : 0ull;
+#pragma unroll
+    for (int i = 15; i >= 0; i--) {
+        if (u0 + (uint32_t)i < lim) {
+            bits16 |= (st & 1u) << i;
+            st = (st >> 1) | ((unsigned)((q[i] >> st) & 1ull) << 5);
+        }
+    }
+}
+// steps 64c .. 64c+63 of a frame are output bytes 8c .. 8c+7, MSB first
+__device__ __forceinline__ void vb_emit(uint8_t *dec, uint32_t c, uint32_t b0, uint32_t b1)
+{
+    uint32_t lo = 0, hi = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        lo |= (__brev((b0 >> (8 * k)) & 0xffu) >> 24) << (8 * k);
+        hi |= (__brev((b1 >> (8 * k)) & 0xffu) >> 24) << (8 * k);
+    }
+    *reinterpret_cast<uint2 *>(dec + 8 * (size_t)c) = make_uint2(lo, hi);
+}
+// the 64-step chunk c of a region of len steps, entered in state st: bits out, state at the chunk's start back
+__device__ __forceinline__ unsigned vb_trace_chunk(const unsigned long long *dwl, uint32_t c, uint32_t len, unsigned st, uint32_t &b0, uint32_t &b1)
+{
+    unsigned long long bits = 0;
+#pragma unroll 1
+    for (int grp = 3; grp >= 0; grp--) {                                   // (rolled: sixteen words in flight, not sixty-four)
+        uint32_t b16 = 0;
+        vb_trace16(dwl, 64u * c + 16u * (uint32_t)grp, len, st, b16);
+        bits |= (unsigned long long)b16 << (16 * grp);
+    }
+    b0 = (uint32_t)bits; b1 = (uint32_t)(bits >> 32);
+    return st;
+}
+
+// ---- traceback: the same lane per work item, all lanes of a wave walking down their blocks together ----
+// A block other than the last one of its frame does not know its end state: it traces the first FX_VB_TWARM steps of the
+// next block from state 0 (the survivors of all states merge within a few constraint lengths) and starts from where that
+// arrives.  fx_vbfinish_kernel checks that guess against the state the next block's traceback really arrived at.
+extern "C" __global__ __launch_bounds__(64)
+void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, uint8_t *bufA,
+                       unsigned long long *dwv, const uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+{
+    const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
+    const uint32_t it0 = first_item + blockIdx.x * 64u;
+    if (it0 >= nitems) return;
+    const uint32_t slot = it0 + threadIdx.x;
+    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
+    if (!__ballot(it.on)) return;
+    const FxPayJob &job = jobs[it.g];
+    const uint32_t len = it.on ? it.t1 - it.t_reg : 0u;
+    uint32_t flags = it.on ? (vb_st[slot] & VB_ST_REP) : 0u;
+    const uint8_t *vec = vec_arena + (size_t)slot * 128u;
+    if (it.on && it.b > 0 && !vb_same64(vec, vec - 64)) flags |= VB_ST_BAD;
+    // the end state: 0 behind the flushed tail, a guess elsewhere
+    const bool has_next = it.on && it.b + 1u < it.nblk;
+    // (dbg bit 0, tests only: no warm-up, the guess is state 0 -- wrong 63 times in 64, for the re-trace path to be exercised)
+    const uint32_t wl = has_next && !(dbg & 1u) ? min((uint32_t)FX_VB_TWARM, min(blk, it.Tn - (it.t_reg + blk))) : 0u;
+    const unsigned long long *dwn = vb_slab(dwv, has_next ? slot + 1u : slot, blk);
+    unsigned S = 0;
+    for (int grp = FX_VB_TWARM / 16 - 1; grp >= 0; grp--) {
+        if (!__any(16u * (uint32_t)grp < wl)) continue;
+        uint32_t unused = 0;
+        vb_trace16(dwn, 16u * (uint32_t)grp, wl, S, unused);
+    }
+    const unsigned long long *dwl = vb_slab(dwv, slot, blk);
+    uint8_t *A = bufA + job.byte_off + it.t_reg / 8u;
+    unsigned st = S;
+    for (int c = (int)(blk / 64u) - 1; c >= 0; c--) {
+        if (!__any(64u * (uint32_t)c < len)) continue;
+        uint32_t b0, b1;
+        st = vb_trace_chunk(dwl, (uint32_t)c, len, st, b0, b1);
+        if (64u * (uint32_t)c < len) vb_emit(A, (uint32_t)c, b0, b1);
+    }
+    if (it.on) vb_st[slot] = S | (st << 8) | flags;
+}
+
+// One block's traceback again, by a whole wave (its end-state guess was wrong): parallel over 64-step chunks with exact
+// verification -- chunk c is first entered from a guess of its end state (chunk c+1 traced back from state 0), then the
+// chain of chunk start states is checked and chunks entered from a wrong state are traced again, to the fixed point.
+// Returns the state at the block's first step.
+__device__ __forceinline__ unsigned vb_retrace_block(const unsigned long long *dwl, uint32_t len, unsigned end_state, uint8_t *dec, uint8_t *scratch, int lane)
+{
+    const uint32_t nchunk = (len + 63) / 64, Lc = nchunk - 1;             // (at most 64 chunks: blk <= 4096)
+    uint8_t *Sarr = scratch, *Barr = scratch + nchunk;                     // (2 len / 64 bytes: the frame's byte buffer holds more than len / 8)
+    const uint32_t c = (uint32_t)lane;
+    if (c < nchunk) {
+        uint32_t b0, b1; unsigned S = end_state;
+        if (c < Lc) S = vb_trace_chunk(dwl, c + 1, len, 0u, b0, b1);
+        const unsigned Bst = vb_trace_chunk(dwl, c, len, S, b0, b1);
+        Sarr[c] = (uint8_t)S; Barr[c] = (uint8_t)Bst; vb_emit(dec, c, b0, b1);
+    }
+    for (;;) {
+        __threadfence_block(); __builtin_amdgcn_wave_barrier();
+        bool redo = false; unsigned need = 0;
+        if (c < nchunk) { need = c == Lc ? end_state : Barr[c + 1]; redo = Sarr[c] != need; }
+        if (!__any(redo)) break;
+        __builtin_amdgcn_wave_barrier();
+        if (redo) {
+            uint32_t b0, b1;
+            const unsigned Bst = vb_trace_chunk(dwl, c, len, need, b0, b1);
+            Sarr[c] = (uint8_t)need; Barr[c] = (uint8_t)Bst; vb_emit(dec, c, b0, b1);
+        }
+    }
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+    return Barr[0];
 }
 
 // ---- front part, one wave per frame: symbols -> packet bytes, de-interleave, fec1 (not convolutional), de-interleave ----
@@ -2526,79 +2696,10 @@ void fx_vbpre_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBloc
     if (lane < 8) B[job.l0 + lane] = 0;
 }
 
-// ---- back part, one wave per frame: verify the blocks' hand-overs (repair where they do not hold), trace back, finish ----
-__device__ __forceinline__ void vb_traceback(const unsigned long long *dw, uint32_t Tn, uint8_t *dec, uint8_t *scratch, int lane)
-{
-    // Parallel over 64-step chunks with exact verification, as in viterbi27: chunk c is first entered from a guess of its end
-    // state (chunk c+1 traced back from state 0), then the chain of chunk start states is checked and chunks entered from a
-    // wrong state are traced again, to the fixed point.  Decision words are one per step here, so their addresses do not
-    // depend on the state: a lane streams its chunk's 64 words.
-    const uint32_t nchunk = (Tn + 63) / 64, Lc = nchunk - 1;
-    uint8_t *Sarr = scratch, *Barr = scratch + nchunk;
-    // (the decision words' addresses do not depend on the state: sixteen of them are fetched at a time, 16-byte loads, and
-    // then walked through from registers -- four memory round trips per chunk instead of sixty-four; the arena has slack
-    // behind the last step, so whole groups are read)
-    auto trace = [&](uint32_t c, unsigned st, uint32_t (&bits)[2]) -> unsigned {
-        const uint32_t t0 = 64u * c, ns = min(64u, Tn - t0);
-        bits[0] = bits[1] = 0u;
-#pragma unroll
-        for (int grp = 3; grp >= 0; grp--) {
-            if ((uint32_t)(16 * grp) >= ns) continue;
-            const ulonglong2 *src = reinterpret_cast<const ulonglong2 *>(dw + t0 + 16u * (uint32_t)grp);
-            ulonglong2 q[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) q[i] = src[i];
-#pragma unroll
-            for (int i = 15; i >= 0; i--) {
-                const int u = 16 * grp + i;
-                if ((uint32_t)u < ns) {
-                    const unsigned long long w = (i & 1) ? q[i >> 1].y : q[i >> 1].x;
-                    bits[u >> 5] |= (st & 1u) << (u & 31);
-                    st = (st >> 1) | ((unsigned)((w >> st) & 1ull) << 5);
-                }
-            }
-        }
-        return st;
-    };
-    auto emit = [&](uint32_t c, const uint32_t (&b)[2]) {
-        uint32_t lo = 0, hi = 0;                                          // steps 64c .. 64c+63 are output bytes 8c .. 8c+7, MSB first
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            lo |= (__brev((b[0] >> (8 * k)) & 0xffu) >> 24) << (8 * k);
-            hi |= (__brev((b[1] >> (8 * k)) & 0xffu) >> 24) << (8 * k);
-        }
-        *reinterpret_cast<uint2 *>(dec + 8 * (size_t)c) = make_uint2(lo, hi);
-    };
-    for (uint32_t base = 0; base < nchunk; base += 64) {
-        const uint32_t c = base + lane;
-        if (c < nchunk) {
-            uint32_t bits[2]; unsigned S = 0;
-            if (c < Lc) S = trace(c + 1, 0u, bits);                        // warm-up through chunk c+1 from state 0
-            const unsigned Bst = trace(c, S, bits);
-            Sarr[c] = (uint8_t)S; Barr[c] = (uint8_t)Bst; emit(c, bits);
-        }
-    }
-    for (;;) {
-        __threadfence_block(); __builtin_amdgcn_wave_barrier();
-        bool changed = false;
-        for (uint32_t base = 0; base < nchunk; base += 64) {
-            const uint32_t c = base + lane;
-            bool redo = false; unsigned need = 0;
-            if (c < nchunk) { need = c == Lc ? 0u : Barr[c + 1]; redo = Sarr[c] != need; }
-            if (redo) {
-                uint32_t bits[2];
-                const unsigned Bst = trace(c, need, bits);
-                Sarr[c] = (uint8_t)need; Barr[c] = (uint8_t)Bst; emit(c, bits);
-            }
-            if (__any(redo)) changed = true;
-        }
-        if (!changed) break;
-    }
-}
-
+// ---- back part, one wave per frame: the chain of traceback states across the frame's blocks, then the frame's tail ----
 extern "C" __global__ __launch_bounds__(64)
-void fx_vbpost_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, uint8_t *bufA, uint8_t *bufB,
-                      unsigned long long *dw_arena, uint8_t *vec_arena, uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_stats)
+void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr, uint32_t first_wave, uint8_t *bufA, uint8_t *bufB,
+                        unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap, uint8_t *out, FxOutRec *recs)
 {
     const uint32_t njobs = hdr->n_dec_batch, blk = hdr->vb_blk;
     const uint32_t ji = first_wave + blockIdx.x;
@@ -2608,27 +2709,32 @@ void fx_vbpost_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
     FxPayJob job = jobs[jf];
     job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
     job.check = __builtin_amdgcn_readfirstlane(job.check); job.vb_nblk = __builtin_amdgcn_readfirstlane(job.vb_nblk);
+    job.vb_off = __builtin_amdgcn_readfirstlane(job.vb_off);
     uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
-    unsigned long long *dw = dw_arena + job.dw_off;
-    uint8_t *vecs = vec_arena + (size_t)job.vb_off * 128u;
-    const uint32_t Tn = 8u * job.k + 6u;
-    const int p = conv_p(job.fec0);
-    // 1. every block's start differences must be the end differences of the block before it; where they are not, the block is
-    //    run again from the true ones (every lane does the same work on the same data: one lane's worth, no exchange needed)
-    uint32_t repaired = 0;                                                   // blocks run again (reported in the frame's status word)
-    for (uint32_t b = 1; b < job.vb_nblk; b++) {
-        const uint8_t *endp = vecs + (size_t)(b - 1) * 128u + 64, *startp = vecs + (size_t)b * 128u;
-        const bool same = endp[lane] == startp[lane];
-        if (__all(same)) continue;
-        const uint32_t t_reg = b * blk, t1 = min(Tn, t_reg + blk);
-        vb_forward(B, p, t_reg, t1, 2, endp, dw, nullptr, vecs + (size_t)b * 128u + 64, blk, 0u, true);
-        __threadfence_block(); __builtin_amdgcn_wave_barrier();
-        repaired++;
+    const uint32_t Tn = 8u * job.k + 6u, at = job.vb_off, nblk = job.vb_nblk;
+    bool bad = false, mism = false; uint32_t rep = 0;
+    for (uint32_t base = 0; base < nblk; base += 64) {
+        const uint32_t b = base + (uint32_t)lane;
+        const uint32_t v = b < nblk ? vb_st[at + b] : 0u, vn = b + 1u < nblk ? vb_st[at + b + 1u] : 0u;
+        bad = bad || (v & VB_ST_BAD);
+        rep += (uint32_t)__popcll(__ballot((v & VB_ST_REP) != 0u));
+        mism = mism || (b + 1u < nblk && (v & 0xffu) != ((vn >> 8) & 0xffu));
     }
-    // 2. trace back into A (k bytes), 3. de-whiten, CRC, payload out
-    vb_traceback(dw, Tn, A, B, lane);
+    if (__any(bad)) {                                                       // an unverified hand-over: the frame is decoded the other way
+        if (lane == 0) { const uint32_t s = atomicAdd(&hdr->n_vb_fallback, 1u); if (s < list_cap) fb_list[s] = jf; }
+        return;
+    }
+    if (__any(mism)) {                                                      // a wrong end-state guess: from the last block downwards
+        unsigned need = (vb_st[at + nblk - 1u] >> 8) & 0xffu;
+        for (int b = (int)nblk - 2; b >= 0; b--) {
+            const uint32_t v = vb_st[at + (uint32_t)b];
+            if ((v & 0xffu) != need) need = vb_retrace_block(vb_slab(dwv, at + (uint32_t)b, blk), blk, need, A + (size_t)b * (blk / 8u), B, lane);
+            else need = (v >> 8) & 0xffu;
+        }
+    }
+    (void)Tn;
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
-    dec_tail(job, jf, A, lane, out, recs, repaired << 8);
+    dec_tail(job, jf, A, lane, out, recs, rep << 8);
 }
 
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
@@ -2638,11 +2744,26 @@ extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hip
     hipLaunchKernelGGL(fx_vbpre_kernel, dim3(n_waves), dim3(DEC_THREADS), 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, T);
     return hipGetLastError();
 }
-extern "C" hipError_t fx_launch_vbpost(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
-                                       uint8_t *bufA, uint8_t *bufB, unsigned long long *dw_arena, uint8_t *vec_arena, uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_stats)
+// forward pass, hand-over check, traceback: the three lane-per-work-item kernels, over the same item slots
+extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
+                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+{
+    if (n_items == 0) return hipSuccess;
+    const dim3 grid((n_items + 63) / 64), block(64);
+    hipLaunchKernelGGL(fx_vbfwd_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
+    // (twice: a block run again may end differently, and then the block behind it has to be run again as well; what two passes
+    // do not settle goes to the wave-per-frame decoder)
+    hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);
+    hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);
+    hipLaunchKernelGGL(fx_vbtrace_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufA, dwv, vec_arena, vb_st, dbg);
+    return hipGetLastError();
+}
+extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
+                                         uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
+                                         uint8_t *out, FxOutRec *recs)
 {
     if (n_waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(fx_vbpost_kernel, dim3(n_waves), dim3(64), 0, st, jobs, job_idx, hdr, first_wave, bufA, bufB, dw_arena, vec_arena, out, recs, hdr_stats);
+    hipLaunchKernelGGL(fx_vbfinish_kernel, dim3(n_waves), dim3(64), 0, st, jobs, job_idx, hdr, first_wave, bufA, bufB, dwv, vb_st, fb_list, list_cap, out, recs);
     return hipGetLastError();
 }
 

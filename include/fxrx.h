@@ -210,6 +210,7 @@ typedef struct {
     uint64_t replays;                            /* carry-buffer overflows / chain repairs handled so far (blocks behind were enqueued again) */
     uint64_t vb_blocks, vb_repairs;              /* batch Viterbi: trellis blocks (incl. padding slots) / blocks run again because a hand-over check failed */
     uint64_t late_decodes;                       /* blocks whose decode launches had to be completed at collect (more frames than the grids were sized for) */
+    uint64_t vb_fallbacks;                       /* batch Viterbi: frames handed back to the wave-per-frame decoder (a hand-over that stayed unverified) */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
 /* the HIP stream (hipStream_t as void*) of the first slot of the ring of blocks in flight; every block runs its whole kernel

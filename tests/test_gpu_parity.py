@@ -735,3 +735,36 @@ def test_soft_decision_demod_and_decode(fx, oracle):
     got += ctx.results(ctx.collect_raw()); got += ctx.results(ctx.collect_raw())
     compare_frames(of, got)
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dbg,blk", [(0, 0), (0, 128), (1, 192), (2, 128), (3, 256)])
+def test_batch_viterbi_repairs_retraces_and_fallbacks(fx, oracle, monkeypatch, dbg, blk):
+    """The batch Viterbi path (lane per trellis block) speculates twice -- a block's warm-up is taken to arrive at the true
+    metric differences, a block's traceback is taken to start from the state a short look-ahead finds -- and verifies both.
+    Low SNR makes the first check fail now and then (fx_vbfix_kernel runs the block again; what two passes do not settle is
+    handed to the wave-per-frame decoder); FXRX_VB_DEBUG bit 0 makes nearly every end-state guess wrong (fx_vbfinish_kernel
+    traces those blocks again), bit 1 leaves every other failed hand-over unrepaired (fallback path).  Every variant,
+    several block lengths and all puncturing classes at once, against the oracle."""
+    cases = [(2, 11, 3.0, 3_000_000, 1024), (27, 15, 9.5, 600_000, 700), (2, 20, 6.5, 600_000, 300), (28, 17, 12.0, 500_000, 2000), (3, 19, 7.0, 400_000, 50)]
+    xs = [fx.synth_stream(n, stream_id=900 + i, mod=m, fec0=f0, payload_len=pl, snr_db=snr)[0] for i, (m, f0, snr, n, pl) in enumerate(cases)]
+    monkeypatch.setenv("FXRX_VB_DEBUG", str(dbg))
+    if blk: monkeypatch.setenv("FXRX_VB_BLK", str(blk))
+    ctx = fx.RxContext(len(xs), want_framesyms=True)
+    gf = ctx.process(xs)
+    tm = ctx.timing()
+    gf2 = ctx.process(xs)                                   # (second block: arenas and grids sized from the first one's traffic)
+    tm2 = ctx.timing()
+    ctx.close()
+    n_bad_payloads = 0
+    for s, x in enumerate(xs):
+        of = oracle_frames(oracle, x)
+        compare_frames(of, [g for g in gf if g["stream"] == s])
+        n_bad_payloads += sum(1 for f in of if f.header_valid and not f.payload_valid)
+    # the second pass continues the streams (their tails differ), so only count it
+    assert tm["vb_blocks"] > 0 and tm2["vb_blocks"] > 0
+    assert n_bad_payloads > 10, "every payload decoded: the SNRs are too kind"
+    print("repairs", tm["vb_repairs"], "fallbacks", tm["vb_fallbacks"], "blocks", tm["vb_blocks"])
+    if dbg & 2: assert tm["vb_fallbacks"] > 0, "no frame was handed back: the fallback path was not exercised"
+    else: assert tm["vb_repairs"] + tm["vb_fallbacks"] > 0, "no hand-over check failed: the repair path was not exercised"
+    assert len(gf2) > 0
