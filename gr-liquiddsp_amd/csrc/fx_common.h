@@ -178,7 +178,8 @@ struct FxStreamDesc {
 
 enum { FX_BLK_INVALID = 1 /* some stream started from an invalid state: nothing in this block counts */,
        FX_BLK_CARRY_OVERFLOW = 2, FX_BLK_CHAIN_FULL = 4 /* chain table exhausted (sizing bug) */,
-       FX_BLK_NEEDS_REPAIR = 8 /* fx_chainfast_kernel met something only the full-size chain kernel can do (a walk) */ };
+       FX_BLK_NEEDS_REPAIR = 8 /* fx_chainfast_kernel met something that takes a walk: a stream is left without chain and state */,
+       FX_BLK_NEEDS_SLOW = 16 /* ... and not just hand-off misses (which repair rounds mend in parallel): the full-size chain kernel has to */ };
 #define FX_PLL_CLASSES 12
 struct FxBlockHdr {                      // device memory, zeroed at submit; mirrored to the host by fx_plan_kernel
     uint32_t n_runs;                     // verification runs emitted (may exceed the capacity: the excess spans are marked bad)
@@ -187,6 +188,7 @@ struct FxBlockHdr {                      // device memory, zeroed at submit; mir
     uint32_t n_vb_items, vb_blk;         // its forward-pass work items (frame, trellis block) / trellis steps per block
     uint32_t vb_want;                    // work items the block's traffic asked for (those beyond the arena go the wave-per-frame way)
     uint32_t n_vb_fallback;              // frames the batch path could not verify: decoded again by the wave-per-frame decoder
+    uint32_t n_repair_req, pad0_;        // repair rounds: segments queued for a walk from their true start state
     uint32_t pll_cnt[FX_PLL_CLASSES];    // frames per modulation class
     uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
     uint64_t sym_total, byte_total, dw_total, out_total;

@@ -40,14 +40,15 @@
 #include "fx_codec.hpp"
 
 extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
-                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T);
+                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total);
 extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results,
                                            FxFrame *frames, FxBlockHdr *hdr, const FxTables *T);
 extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
                                       FxWalkResult *results, FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap,
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T);
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
-                                          const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair);
+                                          const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair,
+                                          FxWalkJob *jobs_rw, uint32_t *req_list);
 extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
                                      const uint32_t *chain_count, uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                                      uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
@@ -148,6 +149,7 @@ struct Slot {
     DevBuf<FxWalkResult> d_wres; DevBuf<FxFrame> d_frames, d_chain; DevBuf<FxVerifyRun> d_runs;
     DevBuf<FxBlockHdr> d_hdr;                // [0] walk-phase counters (zero between blocks), [1] what the payload kernels read
     DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list, d_vb_items;
+    DevBuf<uint32_t> d_req;                  // repair rounds: segments to be walked again from their true start state
     DevBuf<uint8_t> d_vb_vec;                // batch Viterbi: metric differences at the start and end of every trellis block
     DevBuf<unsigned long long> d_vb_dw;      // its decision words, step-major within the 64 work items of a wave
     DevBuf<uint32_t> d_vb_st;                // traceback states and flags per work item
@@ -166,7 +168,7 @@ struct Slot {
     bool any_late = false;
     uint32_t dec_launched = 0, rs_launched = 0;   // decode waves launched with the chain (lean / Reed-Solomon instance)
     bool force_noskip = false;               // walk this block with the exact detector on every hop (nothing to verify)
-    uint32_t kept_hops = 0, kept_cheap = 0, kept_vhops = 0, kept_vfail = 0;   // walk-phase counters of a block whose back part was run again
+    uint32_t kept_hops = 0, kept_cheap = 0, kept_vhops = 0, kept_vfail = 0, kept_repairs = 0;   // walk-phase counters of a block whose back part was run again
 };
 
 struct fxrx_ctx_s {
@@ -365,7 +367,8 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
     return c->last->n_syms ? c->last->d_framesyms.p : nullptr;
 }
 
-static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full);
+enum { kChainFast = 0, kChainFull = 1, kChainDone = 2 };
+static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode);
 
 // ---- enqueue the whole kernel chain of the block in `sl` (descriptors are rebuilt: a replay calls this again) ----
 static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
@@ -463,7 +466,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     sl.o_list = o_list; sl.o_streams = o_streams;
     const uint32_t list_cap = chain_slots + 64 * FX_PLL_CLASSES;
     if (sl.hp_desc.reserve(desc_bytes) || sl.d_desc.reserve(desc_bytes) || sl.d_wres.reserve(NJ + NS) || sl.d_frames.reserve(frame_slots) ||
-        sl.d_runs.reserve(sl.run_cap) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
+        sl.d_runs.reserve(sl.run_cap) || sl.d_req.reserve(NJ) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
         sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(4 * (size_t)list_cap)) return FXRX_ERR_HIP;
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_framesyms.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
@@ -487,11 +490,11 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     // ---- 3. the chain, front part: walkers and seek verification ----
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(sl.ev[0], st));
-    HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
+    HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
     // the true walkers of continuing streams read the state the previous block's chain kernel leaves
     if (!late.empty()) {
         if (c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
-        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables));
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
     }
     HIP_OK(hipEventRecord(sl.ev[1], st));
     if (!detect && c->skip_seek && !sl.force_noskip)
@@ -501,12 +504,12 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
     if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
     if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(st, c->carry_reader[(b + 1) % 3], 0));
-    return enqueue_back(c, sl, false);
+    return enqueue_back(c, sl, kChainFast);
 }
 
 // ---- back part of the chain: chain kernel, plan, payload stage.  `full`: the full-size chain kernel, which can walk
 // (fxrx_collect runs it for a block whose lean chain kernel reported FX_BLK_NEEDS_REPAIR) ----
-static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
+static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
 {
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
@@ -517,11 +520,12 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, bool full)
     const FxStreamDesc *d_streams = reinterpret_cast<const FxStreamDesc *>(sl.d_desc.p + sl.o_streams);
     const uint32_t chain_slots = sl.chain_cap, list_cap = chain_slots + 64 * FX_PLL_CLASSES;
     FxBlockHdr *hdr = sl.d_hdr.p, *hdr_pay = sl.d_hdr.p + 1;
-    if (full)
+    if (chain_mode == kChainFull)
         HIP_OK(fx_launch_chain(mode, c->cfg.equalizer ? 1 : 0, NS, st, d_streams, d_jobs, (uint32_t)sl.NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
                                hdr, c->chain_slow ? 1u : 0u, c->d_tables));
-    else
-        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u));
+    else if (chain_mode == kChainFast)
+        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u, nullptr, nullptr));
+    // (kChainDone: the repair rounds have stitched the block already)
     HIP_OK(hipEventRecord(sl.ev[3], st));
     c->prev_chain = sl.ev[3];
     HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
@@ -597,7 +601,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     const unsigned nslots = c->depth + 1;
     Slot &sl = *c->slots[c->head];
     sl.out.clear(); sl.timing = fxrx_timing{};
-    sl.kept_hops = sl.kept_cheap = sl.kept_vhops = sl.kept_vfail = 0;
+    sl.kept_hops = sl.kept_cheap = sl.kept_vhops = sl.kept_vfail = sl.kept_repairs = 0;
     sl.force_noskip = c->noskip_left > 0; if (c->noskip_left) c->noskip_left--;
     sl.seq = c->seq;
     sl.x.assign(NS, nullptr); sl.n.assign(n_samples, n_samples + NS); sl.snap.assign(NS, StreamSnap{});
@@ -635,6 +639,41 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
 //    and the tail is copied by hand.
 // Either way the state the block left was marked invalid, so every block behind it did nothing: they are enqueued again,
 // in order, once the state is there.
+// Repair rounds.  The lean chain kernel, asked to, rewrites the job of every segment whose predecessor's hand-off target it
+// cannot find -- start / floor / fresh := the predecessor's hand-off hop state, exact detector on every hop -- and lists
+// those segments; they are walked again, all at once, and the chain kernel runs again: a re-walked segment is entered plainly
+// when its predecessor still hands over that state (it does unless the predecessor was itself re-walked and ended
+// differently: then the next round mends it).  Low SNR is where this matters: marginal detections depend on where the
+// detector's hops happen to fall, so speculative lists and true chain disagree dozens of times per block, and the
+// full-size chain kernel would walk those stretches one after the other.  Returns 0: stitched, 1: leave it to that kernel.
+static int repair_rounds(fxrx_ctx_s *c, Slot &sl)
+{
+    if (c->chain_slow) return 1;
+    const unsigned NS = c->cfg.n_streams;
+    const unsigned mode = c->cfg.mode == FXRX_MODE_DETECTOR ? FX_MODE_DETECT : FX_MODE_FLEXRX;
+    hipStream_t st = sl.st;
+    FxWalkJob *d_jobs = reinterpret_cast<FxWalkJob *>(sl.d_desc.p);
+    const FxStreamDesc *d_streams = reinterpret_cast<const FxStreamDesc *>(sl.d_desc.p + sl.o_streams);
+    FxBlockHdr *hdr = sl.d_hdr.p;
+    for (int round = 0; round < 64; round++) {
+        HIP_OK(hipMemsetAsync(hdr, 0, sizeof(FxBlockHdr), st));
+        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, 0u, d_jobs, sl.d_req.p));
+        FxBlockHdr hh;
+        HIP_OK(hipMemcpyAsync(&hh, hdr, sizeof hh, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (std::getenv("FXRX_DEBUG_ROUNDS")) std::fprintf(stderr, "[fxrx] repair round %d: flags %x requests %u\n", round, hh.flags, hh.n_repair_req);
+        if (!(hh.flags & FX_BLK_NEEDS_REPAIR)) return 0;          // (hdr keeps what the chain kernel left there -- flags, stamps -- for the plan kernel)
+        if ((hh.flags & FX_BLK_NEEDS_SLOW) || hh.n_repair_req == 0 || hh.n_repair_req > sl.NJ) break;
+        HIP_OK(hipMemsetAsync(hdr, 0, sizeof(FxBlockHdr), st));
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, hh.n_repair_req, st, d_jobs, sl.d_req.p, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, hdr, c->d_tables, 1, (uint32_t)sl.NJ));
+        HIP_OK(hipMemcpyAsync(&hh, hdr, sizeof hh, hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        sl.kept_hops += hh.hops; sl.kept_cheap += hh.hops_cheap; sl.kept_repairs += hh.walk_jobs_run ? hh.walk_jobs_run : 0;
+    }
+    HIP_OK(hipMemsetAsync(hdr, 0, sizeof(FxBlockHdr), st));
+    return 1;
+}
+
 static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
 {
     const unsigned NS = c->cfg.n_streams;
@@ -652,7 +691,12 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
                 // verify -- and stay in that mode for the next blocks: the channel will not have improved meanwhile.
                 sl.force_noskip = true; c->noskip_left = 32;
                 if (enqueue_block(c, sl)) return FXRX_ERR_HIP;
-            } else if (enqueue_back(c, sl, true)) return FXRX_ERR_HIP;   // what is left (a hand-off target not in the next list) the full-size chain kernel walks
+            } else {
+                // What is left: hand-off targets that the next segment's list does not hold.  Repair rounds mend those in parallel;
+                // anything else (or a block that does not settle) goes through the full-size chain kernel, one workgroup per stream.
+                const int rr = repair_rounds(c, sl);
+                if (rr < 0 || enqueue_back(c, sl, rr == 0 ? kChainDone : kChainFull)) return FXRX_ERR_HIP;
+            }
             continue;                                   // (its tail may in turn overflow the carry buffer)
         }
         if (!(flags & FX_BLK_CARRY_OVERFLOW)) break;
@@ -807,7 +851,7 @@ int fxrx_collect(fxrx_ctx *c)
         (void)hipEventElapsedTime(&ms, sl.ev[6], sl.ev[7]); t.paydec_ms = ms;
     }
     t.total_ms = t.walk_ms + t.seekverify_ms + t.chain_ms + t.paymf_ms + t.paypll_ms + t.paydec_ms;
-    t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs; t.frames = h.n_frames;
+    t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs + sl.kept_repairs; t.frames = h.n_frames;
     t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops + sl.kept_vhops; t.verify_failures = h.verify_failures + sl.kept_vfail;
     t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays + c->repairs_host;
     t.vb_blocks = h.n_vb_items; t.vb_repairs = vb_rep; t.late_decodes = c->late_decodes; t.vb_fallbacks = h.n_vb_fallback;

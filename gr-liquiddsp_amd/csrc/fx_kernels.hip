@@ -234,17 +234,22 @@ template <class LDS> __device__ __forceinline__ void decode_header_bytes(LDS &L,
 // One walk: the synchroniser's state machine from (start, floor, fresh) of `job` until the job's stop / hand-off / end of
 // data.  Called by the whole workgroup (fx_walk_kernel: once; fx_chain_kernel: for every repair).  L.S (template spectrum)
 // must be loaded; the result record and the frames go to global memory (thread 0), verification runs to `runs`.
-template <int MODE, int WW, bool EQ>
+// EXT (walks of the repair rounds, fx_host.cpp): a hand-off target that the list of the segment it falls in does not hold
+// would only be the next round's repair -- the walker looks it up itself and, if it is not there, carries on through that
+// segment as well (a few times at most, and while its frame table has room).
+template <int MODE, int WW, bool EQ, bool EXT = false>
 __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_index, FxWalkResult *result, FxFrame *frames, FxVerifyRun *runs,
                                          uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, WalkLdsT<WW> &L,
-                                         const float2 (&twA)[7], const float2 (&twB)[7])
+                                         const float2 (&twA)[7], const float2 (&twB)[7],
+                                         const FxWalkJob *all_jobs = nullptr, const FxWalkResult *all_results = nullptr, uint32_t n_jobs_total = 0)
 {
     constexpr int WALK_WAVES = WW, WALK_THREADS = 64 * WW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const XSrc xs = { job.x, job.xa_end, job.n };
     const int64_t n = job.n;
 
-    int64_t pos = job.start, floor_ = job.floor;
+    int64_t pos = job.start, floor_ = job.floor, stop = job.stop;
+    int ext_left = 6;
     bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
     uint32_t nfr = 0, hops = 0, hops_cheap = 0, exact_left = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
     int64_t ho_start = 0, ho_pos = 0; int32_t ho_off = 0; float ho_rxy = 0.0f; uint32_t ho_clear = 0;
@@ -308,7 +313,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         x2_0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x2_0)));
         nfr = __builtin_amdgcn_readfirstlane(nfr); hops = __builtin_amdgcn_readfirstlane(hops); hops_cheap = __builtin_amdgcn_readfirstlane(hops_cheap);
         exact_left = __builtin_amdgcn_readfirstlane(exact_left);
-        if (pos >= job.stop && !in_handoff) {
+        if (pos >= stop && !in_handoff) {
             // a speculative walker that never locked has nothing to hand off (its state is not the chain's)
             if (job.handoff && locked) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }
         }
@@ -318,7 +323,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         // (same differential correlator as the single-hop form below, one window per wave, no block barriers
         // inside; used while at least four hops remain before the segment end / end of data)
         if ((!locked || may_skip) && MODE == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n &&
-            (in_handoff || pos + (WALK_WAVES - 1) * FX_HOP < job.stop)) {
+            (in_handoff || pos + (WALK_WAVES - 1) * FX_HOP < stop)) {
             __syncthreads();
             for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(xs, pos - FX_HOP + i, floor_);
             __syncthreads();
@@ -466,7 +471,29 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         }
 
         const int64_t a0 = pos - FX_HOP + (int64_t)bidx;
-        if (in_handoff) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = pos; ho_clear = floor_ <= a0 ? 1u : 0u; exit_code = FX_EXIT_STOP; break; }
+        if (in_handoff) {
+            bool extend = false;
+            if constexpr (EXT) {
+                if (ext_left > 0 && all_jobs) {
+                    uint32_t k = job_index + 1;                            // the segment the detection falls in (as fx_chain_kernel picks it)
+                    while (k + 1 < n_jobs_total && all_jobs[k + 1].stream == job.stream && a0 >= all_jobs[k].stop + FX_HOP) k++;
+                    if (k < n_jobs_total && all_jobs[k].stream == job.stream) {
+                        const FxFrame *FN = frames + all_jobs[k].frame_base;
+                        const uint32_t nfn = all_results[k].n_frames;
+                        int hit = 0;
+                        if (floor_ <= a0)
+                            for (uint32_t i = tid; i < nfn; i += WALK_THREADS) {
+                                const uint32_t fl = FN[i].flags;
+                                if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == a0 && FN[i].offset == boff) hit = 1;
+                            }
+                        hit = __syncthreads_or(hit);
+                        const int64_t room = (int64_t)job.max_frames - (int64_t)nfr - 8;
+                        if (!hit && room * 600 > all_jobs[k].stop - a0) { extend = true; stop = all_jobs[k].stop; ext_left--; in_handoff = false; }
+                    }
+                }
+            }
+            if (!extend) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = pos; ho_clear = floor_ <= a0 ? 1u : 0u; exit_code = FX_EXIT_STOP; break; }
+        }
         if (nfr >= job.max_frames) { exit_code = FX_EXIT_TABLE_FULL; break; }
         if (a0 + FX_NFFT > n) { exit_code = FX_EXIT_NEED_DATA; break; }
 
@@ -774,10 +801,10 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
     }
 }
 
-template <int MODE, int WW, bool EQ>
+template <int MODE, int WW, bool EQ, bool EXT = false>
 __global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
 void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
-                    FxBlockHdr *hdr, const FxTables *T)
+                    FxBlockHdr *hdr, const FxTables *T, uint32_t n_jobs_total)
 {
     __shared__ WalkLdsT<WW> L;
     const uint32_t ji = job_list[blockIdx.x];
@@ -787,17 +814,20 @@ void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResul
 #pragma unroll
     for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
     for (int i = tid; i < FX_NFFT; i += 64 * WW) L.S[i] = T->S[i];
-    walk_run<MODE, WW, EQ>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB);
+    walk_run<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
 }
 
 // (the equaliser stage is a compile-time variant of the flex_rx walker: the default instance carries none of its code)
 extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
-                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T)
+                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total)
 {
     if (njobs == 0) return hipSuccess;
-    if (mode == FX_MODE_DETECT) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_DETECT, FX_DETECT_WAVES, false>), dim3(njobs), dim3(64 * FX_DETECT_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
-    else if (eq) hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES, true>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
-    else hipLaunchKernelGGL((fx_walk_kernel<FX_MODE_FLEXRX, FX_FLEX_WAVES, false>), dim3(njobs), dim3(64 * FX_FLEX_WAVES), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T);
+#define FX_WALK_LAUNCH(M, W, E, X) hipLaunchKernelGGL((fx_walk_kernel<M, W, E, X>), dim3(njobs), dim3(64 * W), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T, n_jobs_total)
+    if (mode == FX_MODE_DETECT) FX_WALK_LAUNCH(FX_MODE_DETECT, FX_DETECT_WAVES, false, false);
+    else if (ext) { if (eq) FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, true, true); else FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, false, true); }
+    else if (eq) FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, true, false);
+    else FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, false, false);
+#undef FX_WALK_LAUNCH
     return hipGetLastError();
 }
 
@@ -901,8 +931,16 @@ __device__ __forceinline__ void copy_frame(FxFrame *dst, const FxFrame *src)
 //      (first -> successor -> ...), ranked by pointer doubling in LDS -- log2(segments) rounds instead of a pointer chase;
 //   C. compaction, one thread per segment on the chain.
 template <int NT>
+//
+// Segments walked again from a true state (FxWalkJob.pad_ = 1, their start / floor / fresh rewritten: see "repair rounds" in
+// fx_host.cpp) are entered plainly -- from their first frame, nothing spliced -- when the predecessor's hand-off hop state is
+// that very state.  With req_list set, a segment on the chain whose hand-off target the next list does not hold is not only
+// reported: the next segment's job is rewritten to start from the true state and queued for such a walk, and the chain is
+// followed on through it as if the walk had already happened (its tail, and so its own hand-off, rarely changes), so that
+// one round finds all the misses of a stream, not just the first.
 __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const FxWalkJob *jobs, const FxWalkResult *results, const FxFrame *frames, FxFrame *out,
-                                                ChainLds &C, uint32_t &cnt, int64_t &fin_pos, int64_t &fin_floor, bool &fin_fresh)
+                                                ChainLds &C, uint32_t &cnt, int64_t &fin_pos, int64_t &fin_floor, bool &fin_fresh,
+                                                FxWalkJob *jobs_rw = nullptr, uint32_t *req_list = nullptr, FxBlockHdr *hdr_rw = nullptr)
 {
     const int tid = threadIdx.x;
     const uint32_t first = sd.first_job, nj = sd.n_jobs, T = nj;           // T: the list's end marker
@@ -925,14 +963,17 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
             const FxWalkResult &RN = results[first + nxt]; const FxFrame *FN = frames + jobs[first + nxt].frame_base;
             uint32_t found = CHAIN_NONE, eb = 0;
             uint32_t nfn = RN.n_frames, nfe = nfn; if (RN.exit_code == FX_EXIT_PAYLOAD && nfe > 0) nfe--;
+            const FxWalkJob &JN = jobs[first + nxt];
+            uint32_t plain = 0;
+            if (JN.pad_ && R.pos == JN.start && R.floor == JN.floor && (R.fresh != 0) == (JN.fresh != 0)) { found = 0; plain = 1; }
             // A frame is a function of (start, CFO bin) alone only if no sample it reads was masked by a zero-floor: splice
             // only when both floors lie at or below the start; else the segment is walked from the true state.
-            for (uint32_t i = 0; R.handoff_clear && i < nfn && i < CHAIN_NONE; i++) {
+            for (uint32_t i = 0; !plain && R.handoff_clear && i < nfn && i < CHAIN_NONE; i++) {
                 const uint32_t fl = FN[i].flags;
                 if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == R.handoff_start && FN[i].offset == R.handoff_offset) { found = i; skipE = eb; break; }
                 if ((fl & FX_FLAG_EXACT) && i < nfe) eb++;
             }
-            lk = nxt | (found << 11);
+            lk = nxt | (found << 11) | (plain << 23);
         }
         C.lk[j] = lk; C.skip[j] = (uint16_t)skipE; C.m[j] = 0xFFFFu; C.pred[j] = 0xFFFFu;
     }
@@ -943,7 +984,11 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
         if (j < nj) {
             const uint32_t inf = C.info[j], ex = (inf >> 24) & 7u, lk = C.lk[j];
             const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
-            if (!term && ((lk >> 11) & 4095u) != CHAIN_NONE) { jmp = lk & 2047u; w = ((C.info[jmp] >> 12) & 4095u) - C.skip[j]; }
+            const bool hit = ((lk >> 11) & 4095u) != CHAIN_NONE;
+            if (!term && (hit || req_list)) { jmp = lk & 2047u; w = hit ? ((C.info[jmp] >> 12) & 4095u) - C.skip[j] : 0u; }
+            // (a speculative walker that never locked hands nothing over; it is only ever reached through a miss, and the walk
+            // queued for it will carry on into the segments behind it: look for further misses there in the same round)
+            if (req_list && j + 1 < nj && ex == FX_EXIT_STOP && !((inf >> 27) & 1u) && jobs[first + j].handoff) { jmp = j + 1; w = 0; }
         }
         C.jumpA[j] = (uint16_t)jmp; C.accA[j] = w; C.markA[j] = j == 0 ? 1 : 0; C.markB[j] = j == 0 ? 1 : 0; C.P[j] = 0;
     }
@@ -966,7 +1011,7 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
             if (!mr[j]) continue;
             const uint32_t inf = C.info[j], ex = (inf >> 24) & 7u, lk = C.lk[j], found = (lk >> 11) & 4095u;
             const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
-            if (!term && found != CHAIN_NONE) { const uint32_t k = lk & 2047u; C.m[k] = (uint16_t)(found | 0x8000u); C.pred[k] = (uint16_t)j; }
+            if (!term && found != CHAIN_NONE) { const uint32_t k = lk & 2047u; C.m[k] = (uint16_t)(found | (((lk >> 23) & 1u) ? 0u : 0x8000u)); C.pred[k] = (uint16_t)j; }
             if (j == 0) C.m[0] = 0;
         }
         __syncthreads();
@@ -979,15 +1024,26 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
             const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
             bool problem = ((inf >> 29) & 1u) || ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID;
             if (!nothing && ((inf >> 28) & 1u)) problem = true;                        // a skipped hop of its tail seek fires
-            if (!term && ((lk >> 11) & 4095u) == CHAIN_NONE) problem = true;           // target not in the next list: repair
+            if (problem) C.sh[5] = 1;                                                  // (nothing a walk from a hand-off state mends)
+            if (req_list && j + 1 < nj && ex == FX_EXIT_STOP && !((inf >> 27) & 1u) && jobs[first + j].handoff) problem = true;   // (passed through, see above)
+            if (!term && ((lk >> 11) & 4095u) == CHAIN_NONE) {                         // target not in the next list: repair
+                problem = true;
+                if (req_list) {
+                    const uint32_t k = lk & 2047u; const FxWalkResult &R = results[first + j];
+                    FxWalkJob &J = jobs_rw[first + k];
+                    J.start = R.pos; J.floor = R.floor; J.fresh = R.fresh ? 1u : 0u; J.prelock = 0; J.no_skip = 1; J.state_in = nullptr; J.pad_ = 1;
+                    req_list[atomicAdd(&hdr_rw->n_repair_req, 1u)] = first + k;
+                }
+            }
             if (problem) C.sh[0] = 1;
-            const uint32_t contrib = j == 0 ? c0 : ((inf >> 12) & 4095u) - C.skip[C.pred[j]];
+            const uint32_t pj = C.pred[j];
+            const uint32_t contrib = j == 0 ? c0 : ((inf >> 12) & 4095u) - (pj == 0xFFFFu ? 0u : C.skip[pj]);
             const uint32_t upto = c0 + C.P[j];                                         // frames up to and including this segment's
             C.accA[j] = upto - contrib;                                                // (accA is free now: offset of its first frame)
             if (term || problem) { C.sh[1] = j; C.sh[2] = nothing ? 1u : 0u; C.sh[3] = upto; }
         }
         __syncthreads();
-        if (tid == 0 && C.sh[3] > sd.chain_cap) C.sh[0] = 1;
+        if (tid == 0 && !C.sh[0] && C.sh[3] > sd.chain_cap) { C.sh[0] = 1; C.sh[5] = 1; }
         __syncthreads();
     }
     // C.
@@ -1002,7 +1058,7 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
                 const uint32_t fl = F[i].flags;
                 if (!(fl & FX_FLAG_EXACT)) continue;
                 const bool own = !(spliced && i == m);
-                if (own && (fl & FX_FLAG_SPAN_BAD)) C.sh[0] = 1;
+                if (own && (fl & FX_FLAG_SPAN_BAD)) { C.sh[0] = 1; C.sh[5] = 1; }
                 copy_frame(out + o, F + i);
                 if (!own) out[o].rxy = results[first + C.pred[j]].handoff_rxy;          // coarse peak as the true chain saw it
                 o++;
@@ -1064,7 +1120,7 @@ __device__ __forceinline__ bool chain_state_in(const FxStreamDesc &sd, uint32_t 
 #define CHAINFAST_THREADS 256
 extern "C" __global__ __launch_bounds__(CHAINFAST_THREADS)
 void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results, const FxFrame *frames, FxFrame *chain,
-                         uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair)
+                         uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair, FxWalkJob *jobs_rw, uint32_t *req_list)
 {
     __shared__ ChainLds C;
     const uint32_t s = blockIdx.x;
@@ -1073,13 +1129,18 @@ void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, con
     if (!chain_state_in(sd, s, st_in, chain_count, hdr)) return;
     uint32_t cnt = 0; int64_t fin_pos = 0, fin_floor = 0; bool fin_fresh = true;
     const unsigned long long t0_ = __builtin_readcyclecounter();
-    const bool ok = !force_repair && chain_fast_path<CHAINFAST_THREADS>(sd, jobs, results, frames, chain + sd.chain_base, C, cnt, fin_pos, fin_floor, fin_fresh);
+    if (threadIdx.x == 0) C.sh[5] = 0;
+    __syncthreads();
+    const bool ok = !force_repair && chain_fast_path<CHAINFAST_THREADS>(sd, jobs, results, frames, chain + sd.chain_base, C, cnt, fin_pos, fin_floor, fin_fresh,
+                                                                        jobs_rw, req_list, hdr);
     if (s == 0 && threadIdx.x == 0) { hdr->stamp[0] = (uint32_t)(__builtin_readcyclecounter() - t0_); }
     if (!ok) {
         if (threadIdx.x == 0) {
             FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
             *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
-            atomicOr(&hdr->flags, (uint32_t)FX_BLK_NEEDS_REPAIR);
+            // (FX_BLK_NEEDS_SLOW: not -- or not only -- hand-off misses: the full-size chain kernel has to go through it)
+            const bool slow = force_repair || sd.n_jobs > CHAIN_MAXJ || C.sh[5];
+            atomicOr(&hdr->flags, (uint32_t)(FX_BLK_NEEDS_REPAIR | (slow ? FX_BLK_NEEDS_SLOW : 0)));
         }
         return;
     }
@@ -1088,9 +1149,11 @@ void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, con
 }
 
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
-                                          const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair)
+                                          const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair,
+                                          FxWalkJob *jobs_rw, uint32_t *req_list)
 {
-    hipLaunchKernelGGL(fx_chainfast_kernel, dim3(nstreams), dim3(CHAINFAST_THREADS), 0, st, streams, jobs, results, frames, chain, chain_count, hdr, force_repair);
+    hipLaunchKernelGGL(fx_chainfast_kernel, dim3(nstreams), dim3(CHAINFAST_THREADS), 0, st, streams, jobs, results, frames, chain, chain_count, hdr, force_repair,
+                       jobs_rw, req_list);
     return hipGetLastError();
 }
 

@@ -147,3 +147,29 @@ def test_repairs_with_blocks_in_flight_behind_them(fx, oracle):
         got += ctx.results(ctx.collect_raw()); fails += ctx.timing()["verify_failures"]; inflight -= 1
     compare_frames(of, got)
     assert fails > 0 and ctx.timing()["replays"] > 0, "no block needed a repair: the path was not exercised"
+
+
+@pytest.mark.parametrize("snr", [3.0, 4.5])
+def test_low_snr_hand_off_misses_are_mended_in_parallel_rounds(fx, oracle, snr):
+    """Near the detector's threshold, what a walker finds depends on where its hops happen to fall: speculative lists and
+    the true chain disagree many times per block (a third of the headers fail at 3 dB).  fxrx_collect mends those in repair
+    rounds -- every segment whose predecessor's hand-off target is missing is walked again from the true state, all at
+    once, each walk carrying on until it meets a list that holds its hand-off -- instead of one workgroup walking them one
+    after the other.  Continuing blocks, small segments (hundreds of them), against the sequential oracle."""
+    x = fx.synth_stream(3_000_000, stream_id=77, snr_db=snr, payload_len=300)[0]
+    of = oracle_frames(oracle, x)
+    assert sum(1 for f in of if not f.header_valid) > 20 or snr > 4.0
+    ctx = fx.RxContext(1, want_framesyms=True, segment_len=16384)
+    ctx.set_depth(2)
+    cuts = [0, 1_000_000, 2_100_000, len(x)]
+    keep = [np.ascontiguousarray(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    got, inflight, reps = [], 0, 0
+    for pc in keep:
+        if inflight == 2:
+            got += ctx.results(ctx.collect_raw()); reps += ctx.timing()["repairs"]; inflight -= 1
+        ctx.submit_raw([pc.ctypes.data], [len(pc)], False); inflight += 1
+    while inflight:
+        got += ctx.results(ctx.collect_raw()); reps += ctx.timing()["repairs"]; inflight -= 1
+    compare_frames(of, got)
+    assert reps > 0, "no hand-off miss: the repair rounds were not exercised"
+    ctx.close()
