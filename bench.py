@@ -365,9 +365,14 @@ def main(argv=None):
         ctx2.close()
 
     if rank == 0:
-        names = dict(walk_ms="fx_walk_kernel", seekverify_ms="fx_seekverify_kernel", chain_ms="fx_chain_kernel+fx_plan_kernel", paymf_ms="fx_paymf_kernel",
-                     paypll_ms="fx_paypll_kernel", paydec_ms="fx_paydec_kernel")
-        dom = max(names, key=lambda k: live[k])
+        # HIP events bracket the stages of a block's kernel chain.  Four stages are a single kernel; the stitch stage is two small
+        # ones and the decode stage six (batch Viterbi: front part, forward pass, hand-over check x2, traceback, back part, plus
+        # the wave-per-frame decoder for what that path does not take).  The roofline line is quoted for the single kernel that
+        # holds the largest share of GPU time in the rocprofv3 summary of this command (profiles/): the PLL, also the longest
+        # stage of a block on its own.
+        names = dict(walk_ms="fx_walk_kernel", seekverify_ms="fx_seekverify_kernel", chain_ms="fx_chainfast_kernel+fx_plan_kernel", paymf_ms="fx_paymf_kernel",
+                     paypll_ms="fx_paypll_kernel", paydec_ms="decode stage (fx_vbpre/vbfwd/vbfix/vbtrace/vbfinish_kernel + fx_paydec_kernel)")
+        dom = max(("walk_ms", "seekverify_ms", "paymf_ms", "paypll_ms"), key=lambda k: live[k])
         alg_bytes = BYTES_PER_SAMPLE * a.samples
         achieved = alg_bytes / (live[dom] * 1e-3) / 1e9
         out = {

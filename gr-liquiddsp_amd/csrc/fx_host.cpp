@@ -188,6 +188,7 @@ struct fxrx_ctx_s {
     uint64_t plain_hint = 0, batch_hint = 0, vb_items_hint = 0, vb_steps_hint = 0, vb_want_hint = 0;   // likewise: frames of the wave-per-frame / batch decoders, trellis blocks, trellis steps
     bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
+    uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
     uint32_t vb_debug = 0, vb_blk_force = 0;   // tests: FXRX_VB_DEBUG (see fx_vbfix_kernel / fx_vbtrace_kernel), FXRX_VB_BLK (trellis steps per block)
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
@@ -317,6 +318,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VB_DEBUG")) c->vb_debug = (uint32_t)std::atoi(e);
     // (a block is at least as long as the warm-up of the next one: 128 steps)
     if (const char *e = std::getenv("FXRX_VB_BLK")) if (std::atoi(e) > 0) c->vb_blk_force = (uint32_t)std::min(4096, std::max(128, (std::atoi(e) + 63) / 64 * 64));
@@ -384,10 +386,15 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         uint64_t tot = 0;
         for (unsigned s = 0; s < NS; s++) tot += sl.n[s];
         // Walker workgroups resident at once: two per CU for the flex_rx instance (4 waves x 256 VGPRs each), two for the
-        // leaner detector-only instance.  Little work: a single round of workgroups with a small margin (the kernel
-        // then lasts as long as its slowest segment).  Lots of work: ~4 rounds so that uneven segments even out.
-        const uint64_t slots = (uint64_t)c->n_cus * 2u;
-        if (tot / slots < 131072) seg = tot / (slots - slots / 16);
+        // leaner detector-only instance.  One block at a time (latency): little work -> a single round of workgroups with a
+        // small margin (the kernel then lasts as long as its slowest segment); lots of work -> ~4 rounds so that uneven
+        // segments even out.  Several blocks in flight (throughput): every segment start costs a speculative walker a
+        // pre-lock scan of half a frame on average -- about as much as two frames' worth of real work -- and the chip is
+        // kept busy by the other blocks anyway, so fewer, longer segments: down to one workgroup per two CUs.
+        const uint64_t slots = (uint64_t)c->n_cus * c->walk_per_cu;
+        // (about three blocks' walkers overlap at any time: keep that many workgroups' worth of segments between them)
+        if (c->depth > 1 && !detect) seg = tot / std::max<uint64_t>(std::max<uint64_t>(1, c->n_cus / 2), std::min<uint64_t>(slots, 3 * slots / c->depth));
+        else if (tot / slots < 131072) seg = tot / (slots - slots / 16);
         else seg = std::max<uint64_t>(tot / (4 * slots), 65536);
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
     }

@@ -14,7 +14,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
-def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
+def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16, pipeline=True):
     xs, inj = [], []
     for i in range(distinct):
         x, f = gen(i, n_samples)
@@ -47,7 +47,7 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
     tm = ctx.timing()
     # the same passes with several in flight (each pass is an independent capture of all streams: reset in between)
     depth = 4
-    ctx.set_depth(depth)
+    if pipeline: ctx.set_depth(depth)
     acc = {}
     def collect():
         ctx.collect_raw()
@@ -62,14 +62,16 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
             ctx.reset(); ctx.submit_raw(ptrs, counts, True); infl += 1
         while infl:
             collect(); infl -= 1
-    pipelined(depth); acc.clear()
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    pipelined(3 * passes)
-    torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / (3 * passes)
+    dtp = float("nan")
+    if pipeline:
+        pipelined(depth); acc.clear()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        pipelined(3 * passes)
+        torch.cuda.synchronize(); dtp = (time.perf_counter() - t0) / (3 * passes)
     out = dict(config=name, streams=n_streams, samples_per_stream=n_samples, frames=len(res), checked_streams=min(n_streams, distinct),
                injected=n_inj, found=n_found, payload_ok=n_bytes_ok, all_frames_ok=bool(ok),
                ms_per_pass=round(dt * 1e3, 3), msamples_per_s=round(n_streams * n_samples / dt / 1e6, 1),
-               ms_per_pass_4_in_flight=round(dtp * 1e3, 3), msamples_per_s_4_in_flight=round(n_streams * n_samples / dtp / 1e6, 1),
+               ms_per_pass_4_in_flight=(round(dtp * 1e3, 3) if pipeline else None), msamples_per_s_4_in_flight=(round(n_streams * n_samples / dtp / 1e6, 1) if pipeline else None),
                kernels_ms={k: round(tm[k], 3) for k in ("walk_ms", "seekverify_ms", "chain_ms", "paymf_ms", "paypll_ms", "paydec_ms")},
                in_flight_sums={k: round(v, 3) for k, v in acc.items()},
                hops=tm["hops"], hops_cheap=tm["hops_cheap"], walk_jobs=tm["walk_jobs"], repairs=tm["repairs"])
@@ -79,19 +81,19 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16):
 
 
 def main():
-    ap = argparse.ArgumentParser(); ap.add_argument("--passes", type=int, default=5); ap.add_argument("--only", default="")
+    ap = argparse.ArgumentParser(); ap.add_argument("--passes", type=int, default=5); ap.add_argument("--only", default=""); ap.add_argument("--no-pipeline", action="store_true")
     a = ap.parse_args()
     import torch
     fx = importlib.import_module("gr-liquiddsp_amd")
     mods, inner = [2, 27, 28, 29], fx.INNER_BY_INDEX
     cfgs = {
         "3": lambda: run(fx, torch, "3: frame_detector_cc, 256 x 2^20", 256, 1 << 20,
-                         lambda i, n: fx.synth_stream(n, stream_id=3000 + i), fx.MODE_DETECTOR, a.passes),
+                         lambda i, n: fx.synth_stream(n, stream_id=3000 + i), fx.MODE_DETECTOR, a.passes, pipeline=not a.no_pipeline),
         "4": lambda: run(fx, torch, "4: flex_rx 128 x 2^21, QAM16 r2/3", 128, 1 << 21,
-                         lambda i, n: fx.synth_stream(n, stream_id=4000 + i, mod=27, fec0=15, snr_db=25.0), fx.MODE_FLEX_RX, a.passes),
+                         lambda i, n: fx.synth_stream(n, stream_id=4000 + i, mod=27, fec0=15, snr_db=25.0), fx.MODE_FLEX_RX, a.passes, pipeline=not a.no_pipeline),
         "5": lambda: run(fx, torch, "5 (one GPU's share): 128 x 2^20, mod/FEC sweep", 128, 1 << 20,
                          lambda i, n: fx.synth_stream(n, stream_id=5000 + i, mod=mods[i % 4], fec0=inner[i % 7], snr_db=32.0),
-                         fx.MODE_FLEX_RX, a.passes, distinct=28),
+                         fx.MODE_FLEX_RX, a.passes, distinct=28, pipeline=not a.no_pipeline),
     }
     for k, f in cfgs.items():
         if not a.only or k in a.only.split(","):
