@@ -123,10 +123,11 @@ struct StreamState {
     int64_t total = 0;                      // absolute index of the next new sample (since the last reset)
     bool fresh_start = true;                // the next block starts from a freshly reset synchroniser (no state to read)
     int64_t carry_bound = 0;                // upper bound of the tail the next block will find (sizes its arenas)
+    unsigned noskip_left = 0;               // blocks this stream is still walked with the exact detector on every hop (a skipped hop fired recently; survives a reset)
 };
 
 // what a block needs to know about a stream at submit time (kept for a replay)
-struct StreamSnap { int64_t tot0 = 0; bool fresh_start = true; int64_t carry_bound = 0; };
+struct StreamSnap { int64_t tot0 = 0; bool fresh_start = true; int64_t carry_bound = 0; bool noskip = false; };
 
 }  // namespace
 
@@ -429,7 +430,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
             j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && cont ? (uint64_t)sn.carry_bound : 0u));
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
-            j.no_skip = (detect || !c->skip_seek || sl.force_noskip) ? 1u : 0u;
+            j.no_skip = (detect || !c->skip_seek || sl.force_noskip || sn.noskip) ? 1u : 0u;
             j.state_in = (first && cont) ? sd.state_in : nullptr;
             j.stream = s; j.verify_per = c->verify_per; j.eq = (!detect && c->cfg.equalizer) ? 1u : 0u;
             (first && cont ? late : early).push_back((uint32_t)jobs.size());
@@ -455,16 +456,22 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     sl.mf_cap = (uint32_t)std::min<uint64_t>(span / 2 / 1024 + chain_slots + 16, 0x7fffffffu);
     // batch Viterbi: trellis steps per block from the traffic of the last block.  The forward pass is arithmetic bound, three
     // waves to a SIMD: some six waves per SIMD spread evenly over the chip, fewer and the slowest SIMD sets the time; blocks
-    // shorter than a few warm-ups waste their work (with several blocks in flight the chip is full anyway: longer blocks).
+    // shorter than a couple of warm-ups waste their work.  (Longer blocks with several blocks in flight -- less warm-up, the
+    // chip is full anyway -- measured worse: 192 steps 30.0, 256: 29.8, 384: 28.8, 512: 27.6, 1024: 24.6 Gsamples/s on config 2.)
     {
         const uint64_t want_items = 64ull * 4ull * (uint64_t)c->n_cus * 6ull;
         sl.vb_blk = (detect || c->cfg.soft_decision || !c->batch_viterbi) ? 0u
-                  : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(c->depth > 1 ? 512 : 192, ((c->vb_steps_hint / want_items + 63) / 64) * 64));
+                  : (uint32_t)std::min<uint64_t>(4096, std::max<uint64_t>(192, ((c->vb_steps_hint / want_items + 63) / 64) * 64));
     }
     if (sl.vb_blk && c->vb_blk_force) sl.vb_blk = c->vb_blk_force;
-    // (arena: what the last block's traffic asked for plus a margin, at least a sample's worth of steps per sample; frames
-    // whose work items do not fit are decoded by the wave-per-frame kernel, and the next block's arena is larger)
-    sl.vb_cap = sl.vb_blk ? (uint32_t)((std::min<uint64_t>(std::max<uint64_t>(span / sl.vb_blk, c->vb_want_hint + c->vb_want_hint / 4) + 1024, 4 * span / sl.vb_blk + 1024) + 63) & ~63ull) : 64u;
+    // (arena: 1.5 trellis steps per sample of span -- QPSK r1/2 has 0.47, QAM16 r2/3 1.17 -- or what the last block's traffic
+    // asked for plus a quarter, in work items of the block length chosen above; frames whose work items do not fit are
+    // decoded by the wave-per-frame kernel, and the next block's arena is larger.  Sized in steps, not items, so that a
+    // change of block length does not reallocate gigabytes.)
+    {
+        const uint64_t steps_cap = std::min<uint64_t>(std::max<uint64_t>(span + span / 2, c->vb_steps_hint + c->vb_steps_hint / 4), 4 * span);
+        sl.vb_cap = sl.vb_blk ? (uint32_t)((steps_cap / sl.vb_blk + 2048 + 127) & ~127ull) : 128u;
+    }
     if (sl.sym_cap >= (1ull << 32) || sl.dw_cap >= (1ull << 32)) { set_err("fxrx_submit: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
 
     // ---- 2. memory ----
@@ -625,6 +632,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
             sl.x[s] = sl.d_in[s].p;
         }
         sl.snap[s].tot0 = S.total; sl.snap[s].fresh_start = S.fresh_start; sl.snap[s].carry_bound = S.fresh_start ? 0 : S.carry_bound;
+        sl.snap[s].noskip = S.noskip_left > 0; if (S.noskip_left) S.noskip_left--;
         S.total += (int64_t)nn; S.fresh_start = false;
         S.carry_bound = std::min<int64_t>(S.carry_cap, sl.snap[s].carry_bound + (int64_t)nn);
     }
@@ -671,6 +679,13 @@ static int repair_rounds(fxrx_ctx_s *c, Slot &sl)
         if (std::getenv("FXRX_DEBUG_ROUNDS")) std::fprintf(stderr, "[fxrx] repair round %d: flags %x requests %u\n", round, hh.flags, hh.n_repair_req);
         if (!(hh.flags & FX_BLK_NEEDS_REPAIR)) return 0;          // (hdr keeps what the chain kernel left there -- flags, stamps -- for the plan kernel)
         if ((hh.flags & FX_BLK_NEEDS_SLOW) || hh.n_repair_req == 0 || hh.n_repair_req > sl.NJ) break;
+        {   // streams in which a skipped hop fired: their next blocks are walked with the exact detector on every hop from the start
+            std::vector<uint32_t> req(hh.n_repair_req);
+            HIP_OK(hipMemcpyAsync(req.data(), sl.d_req.p, req.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            const FxWalkJob *hj = reinterpret_cast<const FxWalkJob *>(sl.hp_desc.p);
+            for (uint32_t r : req) if ((r & 0x80000000u) && (r & 0x7fffffffu) < sl.NJ) c->st[hj[r & 0x7fffffffu].stream].noskip_left = 32;
+        }
         HIP_OK(hipMemsetAsync(hdr, 0, sizeof(FxBlockHdr), st));
         HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, hh.n_repair_req, st, d_jobs, sl.d_req.p, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, hdr, c->d_tables, 1, (uint32_t)sl.NJ));
         HIP_OK(hipMemcpyAsync(&hh, hdr, sizeof hh, hipMemcpyDeviceToHost, st));
@@ -685,15 +700,31 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
 {
     const unsigned NS = c->cfg.n_streams;
     const unsigned nslots = c->depth + 1;
+    // Blocks behind this one that continue its streams started from the state it failed to leave: they are enqueued again
+    // afterwards (and are drained first: a true walker must not read a state entry while it is being rewritten).  Blocks whose
+    // streams all start afresh (separate captures) never looked at it; they, and whatever continues *them*, run on untouched.
+    unsigned n_dep = 0;
+    for (unsigned k = 1; k < c->inflight; k++) {
+        const Slot &nx = *c->slots[(c->tail + k) % nslots];
+        bool dep = false;
+        for (unsigned s = 0; s < NS; s++) dep = dep || !nx.snap[s].fresh_start;
+        if (!dep) break;
+        n_dep++;
+    }
+    const hipEvent_t newest_chain = c->prev_chain;
+    bool carry_moved = false;
     for (int round = 0; round < 6; round++) {
-        for (auto &s : c->slots) if (s->busy) HIP_OK(hipStreamSynchronize(s->st));
+        HIP_OK(hipStreamSynchronize(sl.st));
+        for (unsigned k = 1; k <= n_dep; k++) HIP_OK(hipStreamSynchronize(c->slots[(c->tail + k) % nslots]->st));
         const uint32_t flags = sl.h_hdr.p->flags;
+        if (std::getenv("FXRX_DEBUG_ROUNDS")) std::fprintf(stderr, "[fxrx] block %llu at collect: flags %x verify_failures %u (pass %d)\n", (unsigned long long)sl.seq, flags, sl.h_hdr.p->verify_failures, round);
         if (flags & FX_BLK_NEEDS_REPAIR) {
             c->repairs_host++;
             const FxBlockHdr &h0 = *sl.h_hdr.p;         // the walk-phase counters are zeroed with the first plan kernel: keep them
             sl.kept_hops += h0.hops; sl.kept_cheap += h0.hops_cheap; sl.kept_vhops += h0.verify_hops; sl.kept_vfail += h0.verify_failures;
-            if (!sl.force_noskip && c->cfg.mode != FXRX_MODE_DETECTOR && c->skip_seek && h0.verify_failures) {
-                // Skipped hops on which the exact detector fires (weak preambles, false alarms: low SNR).  Walk the block
+            if (!sl.force_noskip && c->cfg.mode != FXRX_MODE_DETECTOR && c->skip_seek && h0.verify_failures > std::max<uint32_t>(16u, (uint32_t)sl.NJ / 8u)) {
+                // Skipped hops on which the exact detector fires, all over the block (weak preambles, false alarms: low SNR; a
+                // few of them are mended segment by segment in the repair rounds below).  Walk the block
                 // again, all segments in parallel, with the exact detector on every hop -- exact by itself, nothing to
                 // verify -- and stay in that mode for the next blocks: the channel will not have improved meanwhile.
                 sl.force_noskip = true; c->noskip_left = 32;
@@ -709,6 +740,8 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
         if (!(flags & FX_BLK_CARRY_OVERFLOW)) break;
         const uint64_t b = sl.seq;
         FxStreamState *hs = c->h_state + (b % kStateRing) * NS, *ds = c->d_state + (b % kStateRing) * NS;
+        for (auto &o : c->slots) if (o->busy) HIP_OK(hipStreamSynchronize(o->st));      // (carry buffers are about to move under every block in flight)
+        carry_moved = true;
         for (unsigned s = 0; s < NS; s++) {
             if (!hs[s].overflow) continue;
             StreamState &S = c->st[s];
@@ -734,12 +767,14 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
     if (sl.h_hdr.p->flags & (FX_BLK_NEEDS_REPAIR | FX_BLK_CARRY_OVERFLOW)) { set_err("fxrx_collect: block could not be repaired"); return FXRX_ERR_STATE; }
     // the blocks behind it, oldest first (descriptors are rebuilt: carry buffers may have moved)
     c->prev_chain = sl.ev[3];
-    for (unsigned k = 1; k < c->inflight; k++) {
+    const unsigned n_replay = carry_moved ? c->inflight - 1 : n_dep;
+    for (unsigned k = 1; k <= n_replay; k++) {
         Slot &nx = *c->slots[(c->tail + k) % nslots];
         for (unsigned s = 0; s < NS; s++) if (!nx.snap[s].fresh_start) nx.snap[s].carry_bound = c->st[s].carry_cap;
         int r = enqueue_block(c, nx);
         if (r) return r;
     }
+    if (n_replay + 1 < c->inflight) c->prev_chain = newest_chain;      // (the newest block in flight was not touched: the next block waits for its chain)
     for (auto &S : c->st) S.carry_bound = S.carry_cap;
     return 0;
 }

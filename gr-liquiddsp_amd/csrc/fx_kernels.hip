@@ -807,7 +807,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResul
                     FxBlockHdr *hdr, const FxTables *T, uint32_t n_jobs_total)
 {
     __shared__ WalkLdsT<WW> L;
-    const uint32_t ji = job_list[blockIdx.x];
+    const uint32_t ji = job_list[blockIdx.x] & 0x7fffffffu;
     const FxWalkJob job = jobs[ji];
     const int tid = threadIdx.x, lane = tid & 63;
     float2 twA[7], twB[7];
@@ -946,16 +946,29 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
     const uint32_t first = sd.first_job, nj = sd.n_jobs, T = nj;           // T: the list's end marker
     if (nj > CHAIN_MAXJ) return false;
     if (tid < 8) C.sh[tid] = 0;
+    __syncthreads();
     // A.
     for (uint32_t j = tid; j < nj; j += NT) {
         const FxWalkResult &R = results[first + j];
         const FxFrame *F = frames + jobs[first + j].frame_base;
         uint32_t nf = R.n_frames; const uint32_t ex = R.exit_code;
         if (ex == FX_EXIT_PAYLOAD && nf > 0) nf--;
-        uint32_t cntE = 0;
-        for (uint32_t i = 0; i < nf; i++) cntE += (F[i].flags & FX_FLAG_EXACT) ? 1u : 0u;
+        uint32_t cntE = 0; bool badspan = (R.tail_flags & FX_FLAG_SPAN_BAD) != 0;
+        for (uint32_t i = 0; i < nf; i++) {
+            const uint32_t fl = F[i].flags;
+            cntE += (fl & FX_FLAG_EXACT) ? 1u : 0u;
+            badspan = badspan || ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_SPAN_BAD));
+        }
+        // (repair rounds: a segment in which a skipped hop fires is walked again as it was, only with the exact detector on every
+        // hop -- whether or not the chain turns out to pass through the span in question)
+        uint32_t requeued = 0;
+        if (badspan && req_list && !jobs[first + j].no_skip) {
+            jobs_rw[first + j].no_skip = 1;
+            req_list[atomicAdd(&hdr_rw->n_repair_req, 1u)] = (first + j) | 0x80000000u;   // (bit 31: for the host's per-stream bookkeeping)
+            requeued = 1; C.sh[0] = 1;
+        }
         C.info[j] = (nf & 4095u) | ((cntE & 4095u) << 12) | (ex << 24) | ((R.has_handoff ? 1u : 0u) << 27) | (((R.tail_flags & FX_FLAG_SPAN_BAD) ? 1u : 0u) << 28) |
-                    ((nf >= CHAIN_NONE ? 1u : 0u) << 29);
+                    ((nf >= CHAIN_NONE ? 1u : 0u) << 29) | (requeued << 30);
         uint32_t lk = CHAIN_NONE << 11, skipE = 0;
         if (R.has_handoff && ex == FX_EXIT_STOP && j + 1 < nj) {
             uint32_t nxt = j + 1;
@@ -1023,8 +1036,9 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
             const bool spliced = (cm & 0x8000u) != 0, nothing = spliced && nf <= m;
             const bool term = j + 1 == nj || ex != FX_EXIT_STOP || !((inf >> 27) & 1u);
             bool problem = ((inf >> 29) & 1u) || ex == FX_EXIT_TABLE_FULL || ex == FX_EXIT_INVALID;
-            if (!nothing && ((inf >> 28) & 1u)) problem = true;                        // a skipped hop of its tail seek fires
+            if (!nothing && ((inf >> 28) & 1u) && !((inf >> 30) & 1u)) problem = true;  // a skipped hop of its tail seek fires (and the segment is not queued for it)
             if (problem) C.sh[5] = 1;                                                  // (nothing a walk from a hand-off state mends)
+            if ((inf >> 30) & 1u) problem = true;
             if (req_list && j + 1 < nj && ex == FX_EXIT_STOP && !((inf >> 27) & 1u) && jobs[first + j].handoff) problem = true;   // (passed through, see above)
             if (!term && ((lk >> 11) & 4095u) == CHAIN_NONE) {                         // target not in the next list: repair
                 problem = true;
@@ -1380,7 +1394,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
         plan_scan(v, tot, ws);
         // (work items beyond the arena, padding of the seven code classes included: the frame goes the wave-per-frame way, and
         // so does every frame behind it)
-        if (batch && (uint64_t)vb_run + v[6] + vnb + 7u * 64u > vb_cap) { batch = false; vnb = 0; }
+        if (batch && (uint64_t)vb_run + v[6] + vnb + 7u * 128u > vb_cap) { batch = false; vnb = 0; }
         const uint32_t sym_off = sym_run + v[0], byte_off = byte_run + v[1], dw_off = dw_run + v[2], out_off = out_run + v[3], mf_off = mf_run + v[4];
         sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; npj += tot[5]; vb_run += tot[6];
         if (live) {
@@ -1424,7 +1438,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
         for (int c = 0; c < FX_PLL_CLASSES; c++) { cls_base[c] = b; b += (cls_cnt[c] + 63u) & ~63u; }
         cls_base[FX_PLL_CLASSES] = b;
         uint32_t vb = 0;
-        for (int c = 0; c < 7; c++) { vbc_base[c] = vb; vb += (vbc_cnt[c] + 63u) & ~63u; }
+        for (int c = 0; c < 7; c++) { vbc_base[c] = vb; vb += (vbc_cnt[c] + 127u) & ~127u; }   // (whole forward-pass waves: 128 slots)
         vbc_base[7] = vb;
     }
     __syncthreads();
@@ -1454,7 +1468,7 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     if (tid == 0) {
         FxBlockHdr h = *hdr;
         h.n_frames = N; h.n_pjobs = npj; h.n_mfblk = min(mf_run, mf_cap); h.n_dec_plain = dec_cnt[0]; h.n_dec_rs = dec_cnt[1];
-        h.n_dec_batch = dec_cnt[2]; h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk; h.vb_want = vb_run + 7u * 64u; h.n_vb_fallback = 0;
+        h.n_dec_batch = dec_cnt[2]; h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk; h.vb_want = vb_run + 7u * 128u; h.n_vb_fallback = 0;
         for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = cls_cnt[c]; h.pll_base[c] = cls_base[c]; }
         h.pll_base[FX_PLL_CLASSES] = cls_base[FX_PLL_CLASSES];
         h.sym_total = sym_run; h.byte_total = byte_run; h.dw_total = dw_run; h.out_total = out_run;
@@ -2544,6 +2558,144 @@ __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t
 static_assert(FX_VB_WARM <= 128, "trellis blocks are at least 128 steps: a block's warm-up must fit into the block before it");
 #define FX_VB_TWARM 128           // traceback warm-up: steps of the next block traced from state 0 to guess the block's end state
 
+// ---- the forward pass proper: TWO trellis blocks per lane, their doubled metrics side by side in the 16-bit halves of a
+// register.  v_pk_add_u16 / v_pk_min_u16 then serve both: per butterfly and pair of blocks 4 adds, 2 mins, 2 masks (the
+// survivors' parity bits out of the next step's metrics) and 2 x 2 operations that collect the decision bits -- 6
+// instructions per butterfly and trellis block instead of 10.  Halves cannot overflow: metric differences stay below 256,
+// a block and its warm-up are at most 4192 steps of at most 2 each, doubled: < 2^15.
+// A lane's two work items are slots 128 w + l (low halves) and 128 w + 64 + l (high halves): both keep the step-major
+// layout of their own 64-slot slab, so every store is still one contiguous 512-byte piece per half.
+typedef unsigned short vb_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t vb_pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, (vb_u16x2)(__builtin_bit_cast(vb_u16x2, a) + __builtin_bit_cast(vb_u16x2, b)));
+}
+__device__ __forceinline__ uint32_t vb_pk_min(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(vb_u16x2, a), __builtin_bit_cast(vb_u16x2, b)));
+}
+
+// One butterfly of both blocks: predecessors J and J + 32, successors 2J and 2J + 1.  Keys are doubled metrics + 2 cost,
+// + 1 for the predecessor with MSB 1; their minimum is the survivor ("equal -> predecessor with MSB 0") and its LSB the
+// decision bit.  The history word of the successors' group of 16 states takes state 2J + 1 first, then 2J: groups are run
+// through from their highest butterfly down, so that state 16 g + i ends up at bit i of either half.
+template <int J>
+__device__ __forceinline__ void vb2_butterfly(const uint32_t (&Q)[64], uint32_t (&N)[64], const uint32_t (&cc)[4], const uint32_t (&ccp)[4], uint32_t &hist)
+{
+    constexpr unsigned e = vb_expect(J), ne = 3u - e;
+    const uint32_t m0 = vb_pk_min(vb_pk_add(Q[J], cc[e]),  vb_pk_add(Q[J + 32], ccp[ne]));
+    const uint32_t m1 = vb_pk_min(vb_pk_add(Q[J], cc[ne]), vb_pk_add(Q[J + 32], ccp[e]));
+    hist = (hist << 1) | (m1 & 0x00010001u); N[2 * J + 1] = m1 & 0xFFFEFFFEu;
+    hist = (hist << 1) | (m0 & 0x00010001u); N[2 * J] = m0 & 0xFFFEFFFEu;
+}
+template <int G>
+__device__ __forceinline__ uint32_t vb2_group(const uint32_t (&Q)[64], uint32_t (&N)[64], const uint32_t (&cc)[4], const uint32_t (&ccp)[4])
+{
+    uint32_t h = 0;
+    vb2_butterfly<8 * G + 7>(Q, N, cc, ccp, h); vb2_butterfly<8 * G + 6>(Q, N, cc, ccp, h); vb2_butterfly<8 * G + 5>(Q, N, cc, ccp, h); vb2_butterfly<8 * G + 4>(Q, N, cc, ccp, h);
+    vb2_butterfly<8 * G + 3>(Q, N, cc, ccp, h); vb2_butterfly<8 * G + 2>(Q, N, cc, ccp, h); vb2_butterfly<8 * G + 1>(Q, N, cc, ccp, h); vb2_butterfly<8 * G + 0>(Q, N, cc, ccp, h);
+    return h;
+}
+
+// the coded-bit stream of one trellis block: position, puncturing column, a 64-bit window
+struct VbStream { uint32_t col, nb, w0, w1, wbase; };
+// 2 x cost of the four expected pairs e = A | B << 1 against what was received at this step (punctured positions cost nothing)
+__device__ __forceinline__ void vb_costs(VbStream &s, unsigned pa, unsigned pb, unsigned up, bool adv, uint32_t (&c2)[4])
+{
+    const unsigned hasA = (pa >> s.col) & 1u, hasB = (pb >> s.col) & 1u;
+    const unsigned long long w64 = ((unsigned long long)s.w0 << 32) | s.w1;
+    const unsigned top2 = (unsigned)((w64 << ((s.nb - s.wbase) & 63u)) >> 62);
+    const unsigned ra = top2 >> 1, rb = hasA ? (top2 & 1u) : (top2 >> 1);
+    const uint32_t a0 = (hasA & ra) << 1, a1 = (hasA & (ra ^ 1u)) << 1, b0 = (hasB & rb) << 1, b1 = (hasB & (rb ^ 1u)) << 1;
+    c2[0] = a0 + b0; c2[1] = a1 + b0; c2[2] = a0 + b1; c2[3] = a1 + b1;
+    if (adv) { s.nb += hasA + hasB; s.col = s.col + 1u == up ? 0u : s.col + 1u; }
+}
+// One trellis step of both blocks: Q -> N; the decision words of the low-half and of the high-half block.
+__device__ __forceinline__ void vb2_step(const uint32_t (&Q)[64], uint32_t (&N)[64], unsigned pa, unsigned pb, unsigned up, VbStream &sa, VbStream &sb, bool adv_a, bool adv_b,
+                                         unsigned long long &da, unsigned long long &db)
+{
+    uint32_t ca[4], cb[4], cc[4], ccp[4];
+    vb_costs(sa, pa, pb, up, adv_a, ca); vb_costs(sb, pa, pb, up, adv_b, cb);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { cc[i] = ca[i] | (cb[i] << 16); ccp[i] = cc[i] | 0x00010001u; }
+    const uint32_t h0 = vb2_group<0>(Q, N, cc, ccp), h1 = vb2_group<1>(Q, N, cc, ccp), h2 = vb2_group<2>(Q, N, cc, ccp), h3 = vb2_group<3>(Q, N, cc, ccp);
+    // low halves -> the low-half block's word (states 0..63 at bits 0..63), high halves -> the other's
+    const uint32_t al = __builtin_amdgcn_perm(h1, h0, 0x05040100u), ah = __builtin_amdgcn_perm(h3, h2, 0x05040100u);
+    const uint32_t bl = __builtin_amdgcn_perm(h1, h0, 0x07060302u), bh = __builtin_amdgcn_perm(h3, h2, 0x07060302u);
+    da = ((unsigned long long)ah << 32) | al; db = ((unsigned long long)bh << 32) | bl;
+}
+
+// metric differences of one half to its smallest, as bytes (see vb_save_vec; the halves hold doubled metrics)
+__device__ __forceinline__ void vb2_save_vec(const uint32_t (&Q)[64], int half, uint8_t *dst)
+{
+    uint32_t mn = 0xFFFFu;
+#pragma unroll
+    for (int i = 0; i < 64; i++) mn = min(mn, (Q[i] >> (16 * half)) & 0xFFFFu);
+    uint32_t *d = reinterpret_cast<uint32_t *>(dst);
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) w |= min((((Q[4 * i + b] >> (16 * half)) & 0xFFFFu) - mn) >> 1, 255u) << (8 * b);
+        d[i] = w;
+    }
+}
+
+struct VbHalf {                       // one of a lane's two work items
+    const uint8_t *enc; uint32_t t_reg, t1; bool on, first; unsigned long long *dwl; uint8_t *vec;
+};
+
+// Forward pass of a lane's two trellis blocks (same puncturing code p): FX_VB_WARM steps of warm-up from all-equal
+// metrics (a frame's first block idles instead and starts from the encoder's state), then blk region steps whose decisions
+// go to the blocks' slabs; start and end metric differences to the blocks' vector slots.
+__device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A, const VbHalf &B)
+{
+    uint32_t Q[64], N[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) Q[i] = 0u;
+    unsigned pa, pb; vb_punct(p, pa, pb);
+    const unsigned up = (unsigned)p;
+    VbStream sa, sb;
+    {
+        const uint32_t tsa = A.first ? A.t_reg : A.t_reg - FX_VB_WARM, tsb = B.first ? B.t_reg : B.t_reg - FX_VB_WARM;
+        sa.col = tsa % up; sa.nb = (p == 1) ? 2u * tsa : tsa + (tsa + up - 1u) / up; sa.w0 = sa.w1 = sa.wbase = 0;
+        sb.col = tsb % up; sb.nb = (p == 1) ? 2u * tsb : tsb + (tsb + up - 1u) / up; sb.w0 = sb.w1 = sb.wbase = 0;
+    }
+    const uint32_t *ea = reinterpret_cast<const uint32_t *>(A.enc), *eb = reinterpret_cast<const uint32_t *>(B.enc);   // (byte_off is a multiple of 16)
+    const uint32_t nsteps = FX_VB_WARM + blk;
+    for (uint32_t u = 0; u < nsteps; u += 2) {
+        if (u == FX_VB_WARM) {
+            // the encoder's start state for a first block (every other state out of reach: beaten by anything real within
+            // six steps); the record of the start differences for the others
+            if (A.first) {
+#pragma unroll
+                for (int i = 0; i < 64; i++) Q[i] = (Q[i] & 0xFFFF0000u) | (i ? 1024u : 0u);
+            } else if (A.on) vb2_save_vec(Q, 0, A.vec);
+            if (B.first) {
+#pragma unroll
+                for (int i = 0; i < 64; i++) Q[i] = (Q[i] & 0x0000FFFFu) | (i ? 1024u << 16 : 0u);
+            } else if (B.on) vb2_save_vec(Q, 1, B.vec);
+        }
+        if ((u & 15u) == 0u) {                                             // refill the 64-bit windows of coded bits
+            const uint32_t ia = sa.nb >> 5, ib = sb.nb >> 5;
+            const uint32_t x0 = A.on ? ea[ia] : 0u, x1 = A.on ? ea[ia + 1] : 0u, y0 = B.on ? eb[ib] : 0u, y1 = B.on ? eb[ib + 1] : 0u;
+            sa.w0 = __builtin_bswap32(x0); sa.w1 = __builtin_bswap32(x1); sa.wbase = ia << 5;
+            sb.w0 = __builtin_bswap32(y0); sb.w1 = __builtin_bswap32(y1); sb.wbase = ib << 5;
+        }
+        const bool in_reg = u >= FX_VB_WARM;
+        const bool run_a = in_reg || !A.first, run_b = in_reg || !B.first;     // (a block that idles keeps its stream position)
+        unsigned long long a0, b0, a1, b1;
+        vb2_step(Q, N, pa, pb, up, sa, sb, run_a, run_b, a0, b0);
+        vb2_step(N, Q, pa, pb, up, sa, sb, run_a, run_b, a1, b1);
+        // (regions are an even number of steps long within the slab: step ur + 1 is inside it whenever ur is)
+        const uint32_t ur = u - FX_VB_WARM;
+        if (A.on && in_reg && A.t_reg + ur < A.t1) { A.dwl[(size_t)ur * 64u] = a0; A.dwl[(size_t)(ur + 1u) * 64u] = a1; }
+        if (B.on && in_reg && B.t_reg + ur < B.t1) { B.dwl[(size_t)ur * 64u] = b0; B.dwl[(size_t)(ur + 1u) * 64u] = b1; }
+    }
+    if (A.on) vb2_save_vec(Q, 0, A.vec + 64);
+    if (B.on) vb2_save_vec(Q, 1, B.vec + 64);
+}
+
 // ---- forward pass: one lane per (frame, trellis block) work item; the items of a wave share their puncturing code ----
 // vb_items: [0, cap) the frame of every item slot (0xFFFFFFFF: padding of a code class's last wave), [cap, 2 cap) its block
 struct VbItem { uint32_t g, b, t_reg, t1, Tn, nblk; bool on; };
@@ -2563,21 +2715,29 @@ extern "C" __global__ __launch_bounds__(64)
 void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
                      unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st)
 {
+    // (128 item slots per wave: the low-half blocks are slots it0 .. it0 + 63, the high-half blocks the 64 behind them;
+    // code classes are padded to 128 slots, so a wave's items share their puncturing code)
     const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
-    const uint32_t it0 = first_item + blockIdx.x * 64u;
+    const uint32_t it0 = first_item + blockIdx.x * 128u;
     if (it0 >= nitems) return;
-    const uint32_t slot = it0 + threadIdx.x;
-    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
-    const unsigned long long live = __ballot(it.on);
-    if (!live) return;
-    const FxPayJob &job = jobs[it.g];
+    const uint32_t slot_a = it0 + threadIdx.x, slot_b = slot_a + 64u;
+    const VbItem ia = vb_item(jobs, vb_items, item_cap, slot_a, blk);
+    VbItem ib = ia; ib.on = false;
+    if (slot_b < nitems) ib = vb_item(jobs, vb_items, item_cap, slot_b, blk);
+    const unsigned long long live_a = __ballot(ia.on), live_b = __ballot(ib.on);
+    if (!live_a && !live_b) return;
+    const FxPayJob &ja = jobs[ia.g], &jb = jobs[ib.g];
     // (a padding slot has no frame of its own: the wave's code class is read from a live lane)
-    const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)live) - 1, 64));
-    uint8_t *vec = vec_arena + (size_t)slot * 128u;
-    const bool first = !it.on || it.b == 0;
-    vb_st[slot] = 0u;
-    vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, first ? 1 : 0, nullptr, vb_slab(dwv, slot, blk), first ? nullptr : vec, vec + 64,
-               FX_VB_WARM + blk, FX_VB_WARM, it.on);
+    const int p = live_a ? conv_p((unsigned)__shfl((int)ja.fec0, __ffsll((long long)live_a) - 1, 64))
+                         : conv_p((unsigned)__shfl((int)jb.fec0, __ffsll((long long)live_b) - 1, 64));
+    VbHalf A, B;
+    A.enc = bufB + ja.byte_off; A.on = ia.on; A.first = !ia.on || ia.b == 0; A.t_reg = A.first && !ia.on ? 0u : ia.t_reg; A.t1 = ia.t1;
+    A.dwl = vb_slab(dwv, slot_a, blk); A.vec = vec_arena + (size_t)slot_a * 128u;
+    B.enc = bufB + jb.byte_off; B.on = ib.on; B.first = !ib.on || ib.b == 0; B.t_reg = B.first && !ib.on ? 0u : ib.t_reg; B.t1 = ib.t1;
+    B.dwl = vb_slab(dwv, ib.on ? slot_b : slot_a, blk); B.vec = vec_arena + (size_t)(ib.on ? slot_b : slot_a) * 128u;
+    if (ia.on) vb_st[slot_a] = 0u;
+    if (ib.on) vb_st[slot_b] = 0u;
+    vb2_forward(p, blk, A, B);
 }
 
 __device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
@@ -2813,7 +2973,7 @@ extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, h
 {
     if (n_items == 0) return hipSuccess;
     const dim3 grid((n_items + 63) / 64), block(64);
-    hipLaunchKernelGGL(fx_vbfwd_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
+    hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 127) / 128), block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
     // (twice: a block run again may end differently, and then the block behind it has to be run again as well; what two passes
     // do not settle goes to the wave-per-frame decoder)
     hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);

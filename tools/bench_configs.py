@@ -22,6 +22,7 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16, p
     ptrs = [xs[s % distinct].data_ptr() for s in range(n_streams)]
     counts = [n_samples] * n_streams
     ctx = fx.RxContext(n_streams, mode=mode, threshold=0.45 if mode == fx.MODE_DETECTOR else 0.0)
+    ctx.reset(); ctx.process_raw(ptrs, counts, True)            # (twice: the second pass sizes grids and arenas from the first one's traffic)
     ctx.reset(); n = ctx.process_raw(ptrs, counts, True)
     res = ctx.results(n)
     ok = True; n_inj = n_found = n_bytes_ok = 0
@@ -73,6 +74,7 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16, p
                ms_per_pass=round(dt * 1e3, 3), msamples_per_s=round(n_streams * n_samples / dt / 1e6, 1),
                ms_per_pass_4_in_flight=(round(dtp * 1e3, 3) if pipeline else None), msamples_per_s_4_in_flight=(round(n_streams * n_samples / dtp / 1e6, 1) if pipeline else None),
                kernels_ms={k: round(tm[k], 3) for k in ("walk_ms", "seekverify_ms", "chain_ms", "paymf_ms", "paypll_ms", "paydec_ms")},
+               host_ms={k: round(tm[k], 3) for k in ("host_submit_ms", "host_collectwait_ms")}, late_decodes=tm["late_decodes"], replays=tm["replays"],
                in_flight_sums={k: round(v, 3) for k, v in acc.items()},
                hops=tm["hops"], hops_cheap=tm["hops_cheap"], walk_jobs=tm["walk_jobs"], repairs=tm["repairs"])
     print(json.dumps(out), flush=True)
