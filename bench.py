@@ -193,7 +193,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-constellation", action="store_true", help="skip the second figure (payload symbols copied to the host)")
     ap.add_argument("--no-pipeline", action="store_true", help="one block in flight (latency mode)")
-    ap.add_argument("--depth", type=int, default=10, help="blocks in flight in the timed region")
+    ap.add_argument("--depth", type=int, default=12, help="blocks in flight in the timed region")
     ap.add_argument("--segment", type=int, default=0, help="speculation segment length in samples (0 = library default)")
     ap.add_argument("--continuous", action="store_true",
                     help="feed the passes as consecutive blocks of ONE continuing stream (no reset in between): not the headline number")
@@ -369,10 +369,10 @@ def main(argv=None):
         # ones and the decode stage six (batch Viterbi: front part, forward pass, hand-over check x2, traceback, back part, plus
         # the wave-per-frame decoder for what that path does not take).  The roofline line is quoted for the single kernel that
         # holds the largest share of GPU time in the rocprofv3 summary of this command (profiles/): the PLL, also the longest
-        # stage of a block on its own.
+        # stage of a block on its own.  (Fixed, not picked per run: walker and PLL are close under load and would swap places.)
         names = dict(walk_ms="fx_walk_kernel", seekverify_ms="fx_seekverify_kernel", chain_ms="fx_chainfast_kernel+fx_plan_kernel", paymf_ms="fx_paymf_kernel",
                      paypll_ms="fx_paypll_kernel", paydec_ms="decode stage (fx_vbpre/vbfwd/vbfix/vbtrace/vbfinish_kernel + fx_paydec_kernel)")
-        dom = max(("walk_ms", "seekverify_ms", "paymf_ms", "paypll_ms"), key=lambda k: live[k])
+        dom = "paypll_ms"      # (23 % of all kernel time in profiles/r02_bench_kernel_stats.csv; the walker follows with 22 %)
         alg_bytes = BYTES_PER_SAMPLE * a.samples
         achieved = alg_bytes / (live[dom] * 1e-3) / 1e9
         out = {

@@ -272,7 +272,9 @@ struct FxPayJob {           // one per chain frame; nsym == 0: no payload stage 
 
 // batch Viterbi: trellis steps of warm-up a block runs before its own region (survivor paths merge within a few
 // constraint lengths; whether they did is verified, see fx_vbpost_kernel)
+#ifndef FX_VB_WARM
 #define FX_VB_WARM 96
+#endif
 
 struct FxPayResult {        // diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases
     uint32_t stamp[8];

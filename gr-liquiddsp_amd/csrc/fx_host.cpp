@@ -56,7 +56,7 @@ extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
                                       const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, const FxTables *T);
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
-                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg);
+                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed);
 extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
                                          uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
                                          uint8_t *out, FxOutRec *recs);
@@ -159,7 +159,8 @@ struct Slot {
     uint32_t run_cap = 0, chain_cap = 0, mf_cap = 0, frame_slots = 0;
     uint64_t sym_cap = 0, byte_cap = 0, dw_cap = 0, out_cap = 0;
     // payload arenas
-    DevBuf<float2> d_symraw, d_framesyms; DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_soft; DevBuf<unsigned long long> d_dw;
+    DevBuf<float2> d_symraw;                 // matched-filter output; the PLL overwrites it in place with the carrier-recovered symbols
+    DevBuf<uint8_t> d_hard, d_bufA, d_bufB, d_soft; DevBuf<unsigned long long> d_dw;
     // results (pinned host memory the kernels write into)
     PinBuf<FxBlockHdr> h_hdr; PinBuf<FxOutRec> h_recs; PinBuf<uint8_t> h_out, h_soft; PinBuf<float2> h_framesyms;
     std::vector<Out> out;
@@ -367,7 +368,7 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
 {
     if (!c || !c->last) return nullptr;
     if (n) *n = c->last->n_syms;
-    return c->last->n_syms ? c->last->d_framesyms.p : nullptr;
+    return c->last->n_syms ? c->last->d_symraw.p : nullptr;
 }
 
 enum { kChainFast = 0, kChainFull = 1, kChainDone = 2 };
@@ -483,7 +484,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         sl.d_runs.reserve(sl.run_cap) || sl.d_req.reserve(NJ) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
         sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(4 * (size_t)list_cap)) return FXRX_ERR_HIP;
-    if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_framesyms.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
+    if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
                     sl.d_bufA.reserve(sl.byte_cap) || sl.d_bufB.reserve(sl.byte_cap) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.want_framesyms && sl.h_framesyms.reserve(sl.sym_cap)) return FXRX_ERR_HIP;
     if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_cap) ||
@@ -552,7 +553,7 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
         HIP_OK(fx_launch_paymf(mf_grid, c->cfg.equalizer ? 1 : 0, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_chain.p, sl.d_symraw.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[5], st));
         c->carry_reader[b % 3] = sl.ev[5];
-        HIP_OK(fx_launch_paypll((unsigned)(fh / 64 + FX_PLL_CLASSES), c->pll_waves, st, sl.d_pjobs.p, sl.d_pll_list.p, hdr_pay, sl.d_symraw.p, sl.d_framesyms.p,
+        HIP_OK(fx_launch_paypll((unsigned)(fh / 64 + FX_PLL_CLASSES), c->pll_waves, st, sl.d_pjobs.p, sl.d_pll_list.p, hdr_pay, sl.d_symraw.p, sl.d_symraw.p,
                                 sl.d_hard.p, sl.h_recs.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[6], st));
         FxPayResult *pres = nullptr;
@@ -566,7 +567,7 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
         if (soft) {
             // per-bit soft values from the carrier-recovered symbols (data parallel, off the PLL's recurrence); the decoder
             // de-interleaves them in place, so a caller that wants to see them gets a copy first
-            HIP_OK(fx_launch_softdemod(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_framesyms.p, sl.d_hard.p, sl.d_soft.p, c->d_tables));
+            HIP_OK(fx_launch_softdemod(mf_grid, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_symraw.p, sl.d_hard.p, sl.d_soft.p, c->d_tables));
             if (c->cfg.want_framesyms) HIP_OK(hipMemcpyAsync(sl.h_soft.p, sl.d_soft.p, 8 * sl.byte_cap, hipMemcpyDeviceToHost, st));
         }
         // decode: one wave per frame.  The lean instance has no loop (it would double its registers) and an empty workgroup
@@ -582,10 +583,12 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
         // batch Viterbi path (most frames: hard decisions, convolutional fec0): front part, forward pass over trellis blocks, back part
         if (sl.vb_blk) {
             sl.vb_pre_launched = c->first_block ? chain_slots : (unsigned)std::min<uint64_t>(chain_slots, c->batch_hint + c->batch_hint / 2 + 64);
+            // (two work items per lane once the items fill the chip or other blocks do; one per lane for a lone small block)
+            const int vb_packed = (c->depth > 1 || c->vb_items_hint > 64ull * 4ull * (uint64_t)c->n_cus * 3ull / 2ull) ? 1 : 0;
             sl.vb_items_launched = c->first_block ? sl.vb_cap : (unsigned)std::min<uint64_t>(sl.vb_cap, c->vb_items_hint + c->vb_items_hint / 2 + 1024);
             HIP_OK(fx_launch_vbpre(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
             HIP_OK(fx_launch_vbitems(0, sl.vb_items_launched, st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p,
-                                     sl.d_vb_st.p, c->vb_debug));
+                                     sl.d_vb_st.p, c->vb_debug, vb_packed));
             HIP_OK(fx_launch_vbfinish(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
                                       sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p));
             // frames whose hand-overs could not be verified (a repair behind a repair): the wave-per-frame decoder, a few waves
@@ -596,7 +599,7 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
         HIP_OK(hipEventRecord(sl.ev[7], st));
         // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
         if (c->cfg.want_framesyms)
-            HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_framesyms.p, sl.sym_cap * sizeof(float2), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_symraw.p, sl.sym_cap * sizeof(float2), hipMemcpyDeviceToHost, st));
     } else {
         HIP_OK(hipEventRecord(sl.ev[5], st)); HIP_OK(hipEventRecord(sl.ev[6], st)); HIP_OK(hipEventRecord(sl.ev[7], st));
         c->carry_reader[b % 3] = sl.ev[5];
@@ -804,7 +807,7 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
     if (more_batch) {       // (all parts again, for all of the path's frames: they are idempotent -- but for the fallback list, which starts over)
         HIP_OK(hipMemsetAsync(&hdr_pay->n_vb_fallback, 0, sizeof(uint32_t), sl.st));
         HIP_OK(fx_launch_vbpre(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
-        HIP_OK(fx_launch_vbitems(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p, sl.d_vb_st.p, c->vb_debug));
+        HIP_OK(fx_launch_vbitems(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p, sl.d_vb_st.p, c->vb_debug, 1));
         HIP_OK(fx_launch_vbfinish(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
                                   sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p));
         HIP_OK(fx_launch_paydec(0, 0, 0, kFallbackWaves, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,

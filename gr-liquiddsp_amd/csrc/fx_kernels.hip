@@ -2556,7 +2556,9 @@ __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t
 #define VB_ST_BAD 0x10000u        // the block's start differences are not the end differences of the block before it
 #define VB_ST_REP 0x20000u        // ... were not: the block has been run again from the true ones
 static_assert(FX_VB_WARM <= 128, "trellis blocks are at least 128 steps: a block's warm-up must fit into the block before it");
+#ifndef FX_VB_TWARM
 #define FX_VB_TWARM 128           // traceback warm-up: steps of the next block traced from state 0 to guess the block's end state
+#endif
 
 // ---- the forward pass proper: TWO trellis blocks per lane, their doubled metrics side by side in the 16-bit halves of a
 // register.  v_pk_add_u16 / v_pk_min_u16 then serve both: per butterfly and pair of blocks 4 adds, 2 mins, 2 masks (the
@@ -2738,6 +2740,29 @@ void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t it
     if (ia.on) vb_st[slot_a] = 0u;
     if (ib.on) vb_st[slot_b] = 0u;
     vb2_forward(p, blk, A, B);
+}
+
+// The same pass, one work item per lane (32-bit metrics): twice the waves of the packed kernel at about 1.6 x its instructions
+// per block.  Faster when the block's work items do not even fill the chip once (one block in flight: latency), slower as soon
+// as they do.
+extern "C" __global__ __launch_bounds__(64)
+void fx_vbfwd1_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
+                      unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st)
+{
+    const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
+    const uint32_t it0 = first_item + blockIdx.x * 64u;
+    if (it0 >= nitems) return;
+    const uint32_t slot = it0 + threadIdx.x;
+    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
+    const unsigned long long live = __ballot(it.on);
+    if (!live) return;
+    const FxPayJob &job = jobs[it.g];
+    const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)live) - 1, 64));
+    uint8_t *vec = vec_arena + (size_t)slot * 128u;
+    const bool first = !it.on || it.b == 0;
+    if (it.on) vb_st[slot] = 0u;
+    vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, first ? 1 : 0, nullptr, vb_slab(dwv, slot, blk), first ? nullptr : vec, vec + 64,
+               FX_VB_WARM + blk, FX_VB_WARM, it.on);
 }
 
 __device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
@@ -2969,11 +2994,12 @@ extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hip
 }
 // forward pass, hand-over check, traceback: the three lane-per-work-item kernels, over the same item slots
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
-                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed)
 {
     if (n_items == 0) return hipSuccess;
     const dim3 grid((n_items + 63) / 64), block(64);
-    hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 127) / 128), block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
+    if (!packed) hipLaunchKernelGGL(fx_vbfwd1_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
+    else hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 127) / 128), block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
     // (twice: a block run again may end differently, and then the block behind it has to be run again as well; what two passes
     // do not settle goes to the wave-per-frame decoder)
     hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);
