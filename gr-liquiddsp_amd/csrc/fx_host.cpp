@@ -49,10 +49,11 @@ extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, 
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
                                           const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair,
                                           FxWalkJob *jobs_rw, uint32_t *req_list);
-extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
+extern "C" hipError_t fx_launch_plan(hipStream_t st, unsigned grid, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
                                      const uint32_t *chain_count, uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                                      uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
-                                     FxBlockHdr *hdr_host);
+                                     FxBlockHdr *hdr_host, uint32_t *plan_ws);
+extern "C" unsigned fx_plan_ws_words(void);
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
                                       const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, const FxTables *T);
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
@@ -150,6 +151,7 @@ struct Slot {
     DevBuf<FxWalkResult> d_wres; DevBuf<FxFrame> d_frames, d_chain; DevBuf<FxVerifyRun> d_runs;
     DevBuf<FxBlockHdr> d_hdr;                // [0] walk-phase counters (zero between blocks), [1] what the payload kernels read
     DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list, d_vb_items;
+    DevBuf<uint32_t> d_plan_ws;              // plan kernels: look-back state, list counts and cursors (zero between blocks)
     DevBuf<uint32_t> d_req;                  // repair rounds: segments to be walked again from their true start state
     DevBuf<uint8_t> d_vb_vec;                // batch Viterbi: metric differences at the start and end of every trellis block
     DevBuf<unsigned long long> d_vb_dw;      // its decision words, step-major within the 64 work items of a wave
@@ -487,6 +489,10 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
                     sl.d_bufA.reserve(sl.byte_cap) || sl.d_bufB.reserve(sl.byte_cap) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.want_framesyms && sl.h_framesyms.reserve(sl.sym_cap)) return FXRX_ERR_HIP;
+    if (!sl.d_plan_ws.p) {
+        if (sl.d_plan_ws.reserve(fx_plan_ws_words())) return FXRX_ERR_HIP;
+        HIP_OK(hipMemsetAsync(sl.d_plan_ws.p, 0, fx_plan_ws_words() * sizeof(uint32_t), st));
+    }
     if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_cap) ||
         (sl.vb_blk && (sl.d_vb_vec.reserve(128 * (size_t)sl.vb_cap) || sl.d_vb_dw.reserve((size_t)sl.vb_cap * sl.vb_blk) || sl.d_vb_st.reserve(sl.vb_cap)))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.soft_decision && (sl.d_soft.reserve(8 * sl.byte_cap) || (c->cfg.want_framesyms && sl.h_soft.reserve(8 * sl.byte_cap)))) return FXRX_ERR_HIP;
@@ -543,8 +549,10 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
     // (kChainDone: the repair rounds have stitched the block already)
     HIP_OK(hipEventRecord(sl.ev[3], st));
     c->prev_chain = sl.ev[3];
-    HIP_OK(fx_launch_plan(st, d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p, sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p,
-                          sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap, sl.d_vb_items.p, sl.vb_cap, hdr, hdr_pay, sl.h_hdr.p));
+    // (the plan kernels' workgroups take contiguous ranges of the chain's frames: about 2048 each, from the last block's count)
+    HIP_OK(fx_launch_plan(st, (unsigned)std::min<uint64_t>(64, c->frames_hint / 2048 + 1), d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p,
+                          sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p, sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap,
+                          sl.d_vb_items.p, sl.vb_cap, hdr, hdr_pay, sl.h_hdr.p, sl.d_plan_ws.p));
     HIP_OK(hipEventRecord(sl.ev[4], st));
     if (!detect) {
         // grids stride over lists whose lengths only the device knows; size them from what the last block held

@@ -1336,21 +1336,90 @@ __device__ __forceinline__ void plan_scan(uint32_t (&v)[PLAN_NV], uint32_t (&tot
 
 // hdr: the block's walk-phase counters (zeroed again at the end, for the slot's next block); hdr_pay: what the payload kernels
 // read; hdr_host: the host's copy.
-extern "C" __global__ __launch_bounds__(PLAN_THREADS)
-void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain, const uint32_t *chain_count,
-                    uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
-                    uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
-                    FxBlockHdr *hdr_host)
+//
+// Two kernels, each a handful of workgroups over contiguous ranges of the frames (one workgroup took 2 ms for the 38 k frames
+// and 317 k trellis work items of config 4):
+//   fx_plan_kernel       sizes -> arena offsets (prefix sums), jobs, records, matched-filter items, counts per list.  The
+//                        prefix across workgroups is a decoupled look-back: a workgroup publishes the totals of its range,
+//                        then adds up what the workgroups before it have published (their totals, or their inclusive prefix
+//                        once they have one).  It only ever waits for lower-numbered workgroups, which were dispatched first.
+//   fx_planlists_kernel  list slots (the counts are complete: kernel boundary), padding, and -- by the workgroup that
+//                        finishes last -- the block header, its mirrors, and the zeroing of counters and workspace.
+// Workspace (uint32, zero between blocks): [0] finish ticket | [16, 60) counts and fill cursors | [128, 384) look-back flags |
+// [384, 2432) range totals | [2432, 4480) inclusive prefixes
+#define PLAN_MAXG 256
+enum { PW_TICKET = 0, PW_CLS_CNT = 16, PW_DEC_CNT = 28, PW_VBC_CNT = 31, PW_CLS_FILL = 38, PW_DEC_FILL = 50, PW_VBC_FILL = 53,
+       PW_FLAG = 128, PW_AGG = 384, PW_INC = 384 + 8 * PLAN_MAXG, PW_WORDS = 384 + 16 * PLAN_MAXG };
+
+// Wave-aggregated atomic add: the lanes of a wave that add to the same counter counters[key] do so with ONE atomic (38 k
+// frames of one modulation and one code would otherwise queue up on three addresses).  Returns, per active lane, the
+// counter's value before its own contribution, as if the lanes had added one after the other in lane order.  Called by all
+// lanes of the wave (inactive ones pass active = false).
+__device__ __forceinline__ uint32_t wave_agg_add(uint32_t *counters, uint32_t key, uint32_t inc, bool active)
 {
-    // vb_blk: trellis steps per block of the batch Viterbi path (0: path off, e.g. soft decisions); vb_items: [frame | block] x vb_cap
-    __shared__ uint32_t vbc_cnt[7], vbc_base[8], vbc_fill[7];
-    if (threadIdx.x < 7) { vbc_cnt[threadIdx.x] = 0; vbc_fill[threadIdx.x] = 0; }
-    __shared__ uint32_t ws[PLAN_THREADS / 64][PLAN_NV];
-    __shared__ uint32_t cls_cnt[FX_PLL_CLASSES], cls_base[FX_PLL_CLASSES + 1], cls_fill[FX_PLL_CLASSES], dec_cnt[3], dec_fill[3];
+    const int lane = threadIdx.x & 63;
+    unsigned long long rem = __ballot(active);
+    uint32_t result = 0;
+    while (rem) {
+        const int leader = __ffsll((long long)rem) - 1;
+        const uint32_t k = (uint32_t)__shfl((int)key, leader, 64);
+        const bool mine = active && key == k;
+        const unsigned long long same = __ballot(mine);
+        uint32_t incl = mine ? inc : 0u;                                      // inclusive prefix over the lanes of this key
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        const uint32_t total = (uint32_t)__shfl((int)incl, 63, 64);
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counters[k], total);
+        base = (uint32_t)__shfl((int)base, leader, 64);
+        if (mine) result = base + incl - inc;
+        rem &= ~same;
+    }
+    return result;
+}
+
+struct PlanFrame {                      // what both passes of fx_plan_kernel derive from a chain frame
+    const FxFrame *fp; uint32_t sidx, bps, k, l0, l1, nblk, vnb; bool valid, batch;
+};
+__device__ __forceinline__ PlanFrame plan_frame(uint32_t g, bool live, const FxStreamDesc *streams, uint32_t nstreams, const uint32_t *stream_base, const FxFrame *chain,
+                                                uint32_t detect, uint32_t vb_blk, uint32_t (&v)[PLAN_NV])
+{
+    PlanFrame f; f.fp = chain; f.sidx = 0; f.bps = f.k = f.l0 = f.l1 = f.nblk = f.vnb = 0; f.valid = f.batch = false;
+#pragma unroll
+    for (int q = 0; q < PLAN_NV; q++) v[q] = 0;
+    if (!live) return f;
+    uint32_t lo = 0, hi = nstreams;                                          // stream_base[lo] <= g < stream_base[hi]
+    while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (stream_base[mid] <= g) lo = mid; else hi = mid; }
+    f.sidx = lo;
+    const FxFrame *fp = chain + streams[lo].chain_base + (g - stream_base[lo]);
+    f.fp = fp;
+    f.valid = !detect && (fp->flags & FX_FLAG_HEADER_VALID);
+    if (f.valid) {
+        const uint32_t nsym = fp->pay_sym_len, plen = fp->pay_len;
+        f.bps = modem_bps(fp->ms);
+        f.k = plen + crc_len(fp->check); f.l0 = fec_enc_len(fp->fec0, f.k); f.l1 = fec_enc_len(fp->fec1, f.l0);
+        f.nblk = (nsym + 1023u) / 1024u;
+        v[0] = (nsym + 7u) & ~7u;                                           // 8-symbol granules: 64-byte block I/O in the PLL kernel
+        v[1] = (max(f.l1, f.k) + 8u + 15u) & ~15u;
+        v[2] = ((8u * max(f.l0, f.k) + 6u + 63u) & ~63u) + 64u;              // whole 64-step chunks, lane-major
+        v[3] = (plen + 15u) & ~15u;
+        v[4] = f.nblk; v[5] = 1u;
+        // batch Viterbi path: hard decisions, fec0 a K = 7 convolutional code, fec1 neither convolutional nor Reed-Solomon
+        f.batch = vb_blk && conv_p(fp->fec0) && !conv_p(fp->fec1) && fp->fec1 != FX_FEC_RS_M8;
+        if (f.batch) { f.vnb = (8u * f.k + 6u + vb_blk - 1u) / vb_blk; v[6] = f.vnb; }
+    }
+    return f;
+}
+// the frames a workgroup of a plan kernel handles: [g0, g1), whole chunks of PLAN_THREADS
+__device__ __forceinline__ void plan_range(uint32_t N, uint32_t &g0, uint32_t &g1)
+{
+    const uint32_t per = ((N + gridDim.x - 1) / gridDim.x + PLAN_THREADS - 1) / PLAN_THREADS * PLAN_THREADS;
+    g0 = min(N, blockIdx.x * per); g1 = min(N, g0 + per);
+}
+__device__ __forceinline__ uint32_t plan_stream_bases(const uint32_t *chain_count, uint32_t nstreams, uint32_t *stream_base, uint32_t (*ws)[PLAN_NV])
+{
+    // frames before each stream (every workgroup computes and writes the same values)
     const int tid = threadIdx.x;
-    if (tid < FX_PLL_CLASSES) { cls_cnt[tid] = 0; cls_fill[tid] = 0; }
-    if (tid < 3) { dec_cnt[tid] = 0; dec_fill[tid] = 0; }
-    // 1. frames before each stream
     uint32_t run = 0;
     for (uint32_t s0 = 0; s0 < nstreams; s0 += PLAN_THREADS) {
         const uint32_t sidx = s0 + tid;
@@ -1358,63 +1427,86 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
         plan_scan(v, tot, ws);
         if (sidx < nstreams) stream_base[sidx] = run + v[0];
         run += tot[0];
+        __syncthreads();
     }
-    const uint32_t N = run;
-    if (tid == 0) stream_base[nstreams] = N;
+    if (tid == 0) stream_base[nstreams] = run;
     __threadfence(); __syncthreads(); __threadfence();
-    // 2. sizes, offsets, jobs, records, matched-filter items
-    uint32_t sym_run = 0, byte_run = 0, dw_run = 0, out_run = 0, mf_run = 0, npj = 0, vb_run = 0;
-    for (uint32_t g0 = 0; g0 < N; g0 += PLAN_THREADS) {
-        const uint32_t g = g0 + tid;
-        const bool live = g < N;
-        const FxFrame *fp = chain; uint32_t sidx = 0;
-        uint32_t v[PLAN_NV] = { 0, 0, 0, 0, 0, 0, 0 }, tot[PLAN_NV], bps = 0, k = 0, l0 = 0, l1 = 0, nblk = 0, vnb = 0;
-        bool valid = false, batch = false;
-        if (live) {
-            uint32_t lo = 0, hi = nstreams;                                  // stream_base[lo] <= g < stream_base[hi]
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (stream_base[mid] <= g) lo = mid; else hi = mid; }
-            sidx = lo;
-            fp = chain + streams[sidx].chain_base + (g - stream_base[sidx]);
-            valid = !detect && (fp->flags & FX_FLAG_HEADER_VALID);
-            if (valid) {
-                const uint32_t nsym = fp->pay_sym_len, plen = fp->pay_len;
-                bps = modem_bps(fp->ms);
-                k = plen + crc_len(fp->check); l0 = fec_enc_len(fp->fec0, k); l1 = fec_enc_len(fp->fec1, l0);
-                nblk = (nsym + 1023u) / 1024u;
-                v[0] = (nsym + 7u) & ~7u;                                   // 8-symbol granules: 64-byte block I/O in the PLL kernel
-                v[1] = (max(l1, k) + 8u + 15u) & ~15u;
-                v[2] = ((8u * max(l0, k) + 6u + 63u) & ~63u) + 64u;          // whole 64-step chunks, lane-major
-                v[3] = (plen + 15u) & ~15u;
-                v[4] = nblk; v[5] = 1u;
-                // batch Viterbi path: hard decisions, fec0 a K = 7 convolutional code, fec1 neither convolutional nor Reed-Solomon
-                batch = vb_blk && conv_p(fp->fec0) && !conv_p(fp->fec1) && fp->fec1 != FX_FEC_RS_M8;
-                if (batch) { vnb = (8u * k + 6u + vb_blk - 1u) / vb_blk; v[6] = vnb; }
+    return run;
+}
+
+extern "C" __global__ __launch_bounds__(PLAN_THREADS)
+void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain, const uint32_t *chain_count,
+                    uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap, uint32_t vb_cap, uint32_t *pw)
+{
+    // vb_blk: trellis steps per block of the batch Viterbi path (0: path off, e.g. soft decisions)
+    __shared__ uint32_t ws[PLAN_THREADS / 64][PLAN_NV];
+    __shared__ uint32_t base_s[PLAN_NV];
+    const int tid = threadIdx.x;
+    const uint32_t N = plan_stream_bases(chain_count, nstreams, stream_base, ws);
+    uint32_t g0, g1; plan_range(N, g0, g1);
+    const uint32_t wg = blockIdx.x;
+    // 1. totals of the range
+    uint32_t run[PLAN_NV] = { 0, 0, 0, 0, 0, 0, 0 };
+    for (uint32_t c0 = g0; c0 < g1; c0 += PLAN_THREADS) {
+        uint32_t v[PLAN_NV], tot[PLAN_NV];
+        (void)plan_frame(c0 + tid, c0 + tid < g1, streams, nstreams, stream_base, chain, detect, vb_blk, v);
+        plan_scan(v, tot, ws);
+#pragma unroll
+        for (int q = 0; q < PLAN_NV; q++) run[q] += tot[q];
+        __syncthreads();
+    }
+    // 2. what lies before the range
+    if (tid == 0) {
+        uint32_t base[PLAN_NV] = { 0, 0, 0, 0, 0, 0, 0 };
+        if (wg > 0) {
+            for (int q = 0; q < PLAN_NV; q++) pw[PW_AGG + 8 * wg + q] = run[q];
+            __threadfence();
+            __hip_atomic_store(&pw[PW_FLAG + wg], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            for (int p = (int)wg - 1; p >= 0; p--) {
+                uint32_t f;
+                do { f = __hip_atomic_load(&pw[PW_FLAG + p], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); if (!f) __builtin_amdgcn_s_sleep(2); } while (!f);
+                const volatile uint32_t *src = pw + (f == 2u ? PW_INC : PW_AGG) + 8 * p;
+                for (int q = 0; q < PLAN_NV; q++) base[q] += src[q];
+                if (f == 2u) break;
             }
         }
+        for (int q = 0; q < PLAN_NV; q++) { pw[PW_INC + 8 * wg + q] = base[q] + run[q]; base_s[q] = base[q]; }
+        __threadfence();
+        __hip_atomic_store(&pw[PW_FLAG + wg], 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    // 3. jobs, records, matched-filter items, counts
+    uint32_t sym_run = base_s[0], byte_run = base_s[1], dw_run = base_s[2], out_run = base_s[3], mf_run = base_s[4], vb_run = base_s[6];
+    for (uint32_t c0 = g0; c0 < g1; c0 += PLAN_THREADS) {
+        const uint32_t g = c0 + tid;
+        const bool live = g < g1;
+        uint32_t v[PLAN_NV], tot[PLAN_NV];
+        PlanFrame f = plan_frame(g, live, streams, nstreams, stream_base, chain, detect, vb_blk, v);
+        const FxFrame *fp = f.fp;
         plan_scan(v, tot, ws);
         // (work items beyond the arena, padding of the seven code classes included: the frame goes the wave-per-frame way, and
         // so does every frame behind it)
-        if (batch && (uint64_t)vb_run + v[6] + vnb + 7u * 128u > vb_cap) { batch = false; vnb = 0; }
+        if (f.batch && (uint64_t)vb_run + v[6] + f.vnb + 7u * 128u > vb_cap) { f.batch = false; f.vnb = 0; }
         const uint32_t sym_off = sym_run + v[0], byte_off = byte_run + v[1], dw_off = dw_run + v[2], out_off = out_run + v[3], mf_off = mf_run + v[4];
-        sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; npj += tot[5]; vb_run += tot[6];
+        sym_run += tot[0]; byte_run += tot[1]; dw_run += tot[2]; out_run += tot[3]; mf_run += tot[4]; vb_run += tot[6];
         if (live) {
-            const FxStreamDesc &sd = streams[sidx];
+            const FxStreamDesc &sd = streams[f.sidx];
             FxPayJob j;
             j.x = sd.x; j.xa_end = sd.xa_end; j.start = fp->start; j.mix_th = fp->mix_th; j.mix_dl = fp->mix_dl; j.mf_scale = fp->mf_scale;
-            j.pfb = fp->pfb; j.mfc0 = fp->mfc0; j.pll_th = fp->pll_th; j.pll_f = fp->pll_f; j.ms = fp->ms; j.bps = bps;
-            j.nsym = valid ? fp->pay_sym_len : 0u; j.sym_off = sym_off;
-            j.pay_len = fp->pay_len; j.check = fp->check; j.fec0 = fp->fec0; j.fec1 = fp->fec1; j.k = k; j.l0 = l0; j.l1 = l1;
-            j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = valid ? 1u : 0u;
-            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain); j.vb_off = 0; j.vb_nblk = vnb;
+            j.pfb = fp->pfb; j.mfc0 = fp->mfc0; j.pll_th = fp->pll_th; j.pll_f = fp->pll_f; j.ms = fp->ms; j.bps = f.bps;
+            j.nsym = f.valid ? fp->pay_sym_len : 0u; j.sym_off = sym_off;
+            j.pay_len = fp->pay_len; j.check = fp->check; j.fec0 = fp->fec0; j.fec1 = fp->fec1; j.k = f.k; j.l0 = f.l0; j.l1 = f.l1;
+            j.byte_off = byte_off; j.dw_off = dw_off; j.out_off = out_off; j.pad_ = f.valid ? 1u : 0u;
+            j.eq = eq; j.chain_idx = (uint32_t)(fp - chain); j.vb_off = 0; j.vb_nblk = f.vnb;
             pjobs[g] = j;
             // the record goes to pinned host memory: assemble it in registers, send it as eight 16-byte stores
             union { FxOutRec r; uint4 q[sizeof(FxOutRec) / 16]; } u;
-            u.r.start = sd.abs_base + fp->start; u.r.stream = sidx; u.r.offset = fp->offset;
+            u.r.start = sd.abs_base + fp->start; u.r.stream = f.sidx; u.r.offset = fp->offset;
             u.r.rxy = fp->rxy; u.r.tau = fp->tau; u.r.gamma = fp->gamma; u.r.dphi = fp->dphi; u.r.phi = fp->phi; u.r.pfb = fp->pfb;
             u.r.pilot_dphi = fp->pilot_dphi; u.r.pilot_phi = fp->pilot_phi; u.r.pilot_gain = fp->pilot_gain;
             u.r.flags = fp->flags & FX_FLAG_HEADER_VALID;
-            u.r.pay_len = valid ? fp->pay_len : 0u; u.r.ms = fp->ms; u.r.check = fp->check; u.r.fec0 = fp->fec0; u.r.fec1 = fp->fec1;
-            u.r.nsym = valid ? fp->pay_sym_len : 0u; u.r.bps = bps; u.r.sym_off = sym_off; u.r.out_off = out_off;
+            u.r.pay_len = f.valid ? fp->pay_len : 0u; u.r.ms = fp->ms; u.r.check = fp->check; u.r.fec0 = fp->fec0; u.r.fec1 = fp->fec1;
+            u.r.nsym = f.valid ? fp->pay_sym_len : 0u; u.r.bps = f.bps; u.r.sym_off = sym_off; u.r.out_off = out_off;
             u.r.evm_sum = 0.0f; u.r.payload_valid = 0; u.r.status = 0;
             const uint32_t *hw = reinterpret_cast<const uint32_t *>(fp->header); uint32_t *rw = reinterpret_cast<uint32_t *>(u.r.header);
 #pragma unroll
@@ -1423,55 +1515,79 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
             uint4 *dst = reinterpret_cast<uint4 *>(recs + g);
 #pragma unroll
             for (int i = 0; i < (int)(sizeof(FxOutRec) / 16); i++) dst[i] = u.q[i];
-            if (valid) {
-                for (uint32_t c = 0; c < nblk; c++) if (mf_off + c < mf_cap) { mf_job[mf_off + c] = g; mf_c0[mf_off + c] = c * 1024u; }
-                atomicAdd(&cls_cnt[pll_class(fp->ms)], 1u);
-                atomicAdd(&dec_cnt[batch ? 2 : ((fp->fec0 == FX_FEC_RS_M8 || fp->fec1 == FX_FEC_RS_M8) ? 1 : 0)], 1u);
-                if (batch) atomicAdd(&vbc_cnt[conv_p(fp->fec0) - 1], vnb);
+            if (f.valid) {
+                for (uint32_t c = 0; c < f.nblk; c++) if (mf_off + c < mf_cap) { mf_job[mf_off + c] = g; mf_c0[mf_off + c] = c * 1024u; }
             }
         }
+        {   // counts per list (wave-aggregated: one atomic per wave and list)
+            const bool val = live && f.valid;
+            const uint32_t ms = val ? fp->ms : 0u, fec0 = val ? fp->fec0 : 0u, fec1 = val ? fp->fec1 : 0u;
+            (void)wave_agg_add(pw + PW_CLS_CNT, pll_class(ms), 1u, val);
+            (void)wave_agg_add(pw + PW_DEC_CNT, f.batch ? 2u : ((fec0 == FX_FEC_RS_M8 || fec1 == FX_FEC_RS_M8) ? 1u : 0u), 1u, val);
+            (void)wave_agg_add(pw + PW_VBC_CNT, val && f.batch ? (uint32_t)conv_p(fec0) - 1u : 0u, f.vnb, val && f.batch);
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    // 3. PLL lists (one per modulation class, padded to whole waves) and decode lists
+}
+
+extern "C" __global__ __launch_bounds__(PLAN_THREADS)
+void fx_planlists_kernel(uint32_t nstreams, uint32_t vb_blk, uint32_t *stream_base, FxPayJob *pjobs, uint32_t mf_cap, uint32_t *pll_list, uint32_t *dec_list,
+                         uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay, FxBlockHdr *hdr_host, uint32_t *pw)
+{
+    __shared__ uint32_t cls_base[FX_PLL_CLASSES + 1], vbc_base[8], last;
+    const int tid = threadIdx.x;
+    const uint32_t N = stream_base[nstreams];
     if (tid == 0) {
         uint32_t b = 0;
-        for (int c = 0; c < FX_PLL_CLASSES; c++) { cls_base[c] = b; b += (cls_cnt[c] + 63u) & ~63u; }
+        for (int c = 0; c < FX_PLL_CLASSES; c++) { cls_base[c] = b; b += (pw[PW_CLS_CNT + c] + 63u) & ~63u; }   // whole waves
         cls_base[FX_PLL_CLASSES] = b;
         uint32_t vb = 0;
-        for (int c = 0; c < 7; c++) { vbc_base[c] = vb; vb += (vbc_cnt[c] + 127u) & ~127u; }   // (whole forward-pass waves: 128 slots)
+        for (int c = 0; c < 7; c++) { vbc_base[c] = vb; vb += (pw[PW_VBC_CNT + c] + 127u) & ~127u; }            // whole forward-pass waves: 128 slots
         vbc_base[7] = vb;
     }
     __syncthreads();
-    const uint32_t pll_slots = min(cls_base[FX_PLL_CLASSES], list_cap);
-    for (uint32_t i = tid; i < pll_slots; i += PLAN_THREADS) pll_list[i] = 0xFFFFFFFFu;
-    const uint32_t vb_slots = min(vbc_base[7], vb_cap);
-    for (uint32_t i = tid; i < vb_slots; i += PLAN_THREADS) vb_items[i] = 0xFFFFFFFFu;
-    __threadfence(); __syncthreads(); __threadfence();
-    for (uint32_t g = tid; g < N; g += PLAN_THREADS) {
-        const FxPayJob &j = pjobs[g];
-        if (!j.pad_) continue;
-        const unsigned c = pll_class(j.ms);
-        const uint32_t pp = cls_base[c] + atomicAdd(&cls_fill[c], 1u);
-        if (pp < list_cap) pll_list[pp] = g;
-        const int rs = j.vb_nblk ? 2 : ((j.fec0 == FX_FEC_RS_M8 || j.fec1 == FX_FEC_RS_M8) ? 1 : 0);
-        const uint32_t dp = atomicAdd(&dec_fill[rs], 1u);
-        if (dp < list_cap) dec_list[(size_t)rs * list_cap + dp] = g;
-        if (j.vb_nblk) {                                                       // its trellis blocks, among those of the same code
-            const int vc = conv_p(j.fec0) - 1;
-            const uint32_t at = vbc_base[vc] + atomicAdd(&vbc_fill[vc], j.vb_nblk);
-            for (uint32_t b = 0; b < j.vb_nblk; b++) if (at + b < vb_cap) { vb_items[at + b] = g; vb_items[vb_cap + at + b] = b; }
+    uint32_t g0, g1; plan_range(N, g0, g1);
+    for (uint32_t c0 = g0; c0 < g1; c0 += PLAN_THREADS) {                     // (whole chunks: the slot cursors are advanced wave by wave)
+        const uint32_t g = c0 + tid;
+        const bool live = g < g1;
+        uint32_t ms = 0, fec0 = 0, fec1 = 0, vnb = 0; bool val = false;
+        if (live) { const FxPayJob &j = pjobs[g]; val = j.pad_ != 0; ms = j.ms; fec0 = j.fec0; fec1 = j.fec1; vnb = j.vb_nblk; }
+        const unsigned c = pll_class(ms);
+        const uint32_t pp = cls_base[c] + wave_agg_add(pw + PW_CLS_FILL, c, 1u, val);
+        if (val && pp < list_cap) pll_list[pp] = g;
+        const uint32_t rs = vnb ? 2u : ((fec0 == FX_FEC_RS_M8 || fec1 == FX_FEC_RS_M8) ? 1u : 0u);
+        const uint32_t dp = wave_agg_add(pw + PW_DEC_FILL, rs, 1u, val);
+        if (val && dp < list_cap) dec_list[(size_t)rs * list_cap + dp] = g;
+        const bool bt = val && vnb;                                             // its trellis blocks, among those of the same code
+        const uint32_t vc = bt ? (uint32_t)conv_p(fec0) - 1u : 0u;
+        const uint32_t at = vbc_base[vc] + wave_agg_add(pw + PW_VBC_FILL, vc, vnb, bt);
+        if (bt) {
+            for (uint32_t b = 0; b < vnb; b++) if (at + b < vb_cap) { vb_items[at + b] = g; vb_items[vb_cap + at + b] = b; }
             pjobs[g].vb_off = at;
         }
     }
+    if (blockIdx.x == 0) {                                                      // padding slots of every class
+        for (int c = 0; c < FX_PLL_CLASSES; c++)
+            for (uint32_t i = cls_base[c] + pw[PW_CLS_CNT + c] + tid; i < cls_base[c + 1] && i < list_cap; i += PLAN_THREADS) pll_list[i] = 0xFFFFFFFFu;
+        for (int c = 0; c < 7; c++)
+            for (uint32_t i = vbc_base[c] + pw[PW_VBC_CNT + c] + tid; i < vbc_base[c + 1] && i < vb_cap; i += PLAN_THREADS) vb_items[i] = 0xFFFFFFFFu;
+    }
+    // the workgroup that finishes last: block header for the payload kernels and for the host; counters, workspace and the
+    // walk-phase header are zeroed for the slot's next block
+    __threadfence(); __syncthreads();
+    if (tid == 0) last = atomicAdd(&pw[PW_TICKET], 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
-    // 4. block header: for the payload kernels, for the host; the walk-phase counters are zeroed for the slot's next block
+    if (!last) return;
+    __threadfence();
     if (tid == 0) {
+        const volatile uint32_t *tot = pw + PW_INC + 8 * (gridDim.x - 1);
         FxBlockHdr h = *hdr;
-        h.n_frames = N; h.n_pjobs = npj; h.n_mfblk = min(mf_run, mf_cap); h.n_dec_plain = dec_cnt[0]; h.n_dec_rs = dec_cnt[1];
-        h.n_dec_batch = dec_cnt[2]; h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk; h.vb_want = vb_run + 7u * 128u; h.n_vb_fallback = 0;
-        for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = cls_cnt[c]; h.pll_base[c] = cls_base[c]; }
+        h.n_frames = N; h.n_pjobs = tot[5]; h.n_mfblk = min(tot[4], mf_cap);
+        h.n_dec_plain = pw[PW_DEC_CNT + 0]; h.n_dec_rs = pw[PW_DEC_CNT + 1]; h.n_dec_batch = pw[PW_DEC_CNT + 2];
+        h.n_vb_items = min(vbc_base[7], vb_cap); h.vb_blk = vb_blk; h.vb_want = tot[6] + 7u * 128u; h.n_vb_fallback = 0;
+        for (int c = 0; c < FX_PLL_CLASSES; c++) { h.pll_cnt[c] = pw[PW_CLS_CNT + c]; h.pll_base[c] = cls_base[c]; }
         h.pll_base[FX_PLL_CLASSES] = cls_base[FX_PLL_CLASSES];
-        h.sym_total = sym_run; h.byte_total = byte_run; h.dw_total = dw_run; h.out_total = out_run;
+        h.sym_total = tot[0]; h.byte_total = tot[1]; h.dw_total = tot[2]; h.out_total = tot[3];
         h.done = 1;
         *hdr_pay = h;
         *hdr_host = h;
@@ -1480,18 +1596,23 @@ void fx_plan_kernel(const FxStreamDesc *streams, uint32_t nstreams, uint32_t det
     {
         uint32_t *z = reinterpret_cast<uint32_t *>(hdr);
         for (int i = tid; i < (int)(sizeof(FxBlockHdr) / 4); i += PLAN_THREADS) z[i] = 0u;
+        for (int i = tid; i < PW_WORDS; i += PLAN_THREADS) pw[i] = 0u;
     }
 }
 
-extern "C" hipError_t fx_launch_plan(hipStream_t st, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
+extern "C" hipError_t fx_launch_plan(hipStream_t st, unsigned grid, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
                                      const uint32_t *chain_count, uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                                      uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
-                                     FxBlockHdr *hdr_host)
+                                     FxBlockHdr *hdr_host, uint32_t *plan_ws)
 {
-    hipLaunchKernelGGL(fx_plan_kernel, dim3(1), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, eq, vb_blk, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0,
-                       mf_cap, pll_list, dec_list, list_cap, vb_items, vb_cap, hdr, hdr_pay, hdr_host);
+    const unsigned g = grid < 1u ? 1u : (grid > PLAN_MAXG ? PLAN_MAXG : grid);
+    hipLaunchKernelGGL(fx_plan_kernel, dim3(g), dim3(PLAN_THREADS), 0, st, streams, nstreams, detect, eq, vb_blk, chain, chain_count, stream_base, pjobs, recs, mf_job, mf_c0,
+                       mf_cap, vb_cap, plan_ws);
+    hipLaunchKernelGGL(fx_planlists_kernel, dim3(g), dim3(PLAN_THREADS), 0, st, nstreams, vb_blk, stream_base, pjobs, mf_cap, pll_list, dec_list, list_cap, vb_items, vb_cap,
+                       hdr, hdr_pay, hdr_host, plan_ws);
     return hipGetLastError();
 }
+extern "C" unsigned fx_plan_ws_words(void) { return PW_WORDS; }
 
 // ===================================================================== payload: mix + polyphase MF
 #define PMF_THREADS 256
