@@ -193,6 +193,7 @@ struct fxrx_ctx_s {
     bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
+    uint32_t plan_grid = 0;              // FXRX_PLAN_GRID: workgroups of the plan kernels (tests; default: from the last block's frame count)
     uint32_t vb_debug = 0, vb_blk_force = 0;   // tests: FXRX_VB_DEBUG (see fx_vbfix_kernel / fx_vbtrace_kernel), FXRX_VB_BLK (trellis steps per block)
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
     std::vector<std::unique_ptr<Slot>> slots; unsigned depth = 1, head = 0, tail = 0, inflight = 0;
@@ -323,6 +324,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_PLAN_GRID")) c->plan_grid = (uint32_t)std::min(256, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VB_DEBUG")) c->vb_debug = (uint32_t)std::atoi(e);
     // (a block is at least as long as the warm-up of the next one: 128 steps)
     if (const char *e = std::getenv("FXRX_VB_BLK")) if (std::atoi(e) > 0) c->vb_blk_force = (uint32_t)std::min(4096, std::max(128, (std::atoi(e) + 63) / 64 * 64));
@@ -550,7 +552,7 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
     HIP_OK(hipEventRecord(sl.ev[3], st));
     c->prev_chain = sl.ev[3];
     // (the plan kernels' workgroups take contiguous ranges of the chain's frames: about 2048 each, from the last block's count)
-    HIP_OK(fx_launch_plan(st, (unsigned)std::min<uint64_t>(64, c->frames_hint / 2048 + 1), d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p,
+    HIP_OK(fx_launch_plan(st, c->plan_grid ? c->plan_grid : (unsigned)std::min<uint64_t>(64, c->frames_hint / 2048 + 1), d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p,
                           sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p, sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap,
                           sl.d_vb_items.p, sl.vb_cap, hdr, hdr_pay, sl.h_hdr.p, sl.d_plan_ws.p));
     HIP_OK(hipEventRecord(sl.ev[4], st));

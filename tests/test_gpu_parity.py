@@ -768,3 +768,34 @@ def test_batch_viterbi_repairs_retraces_and_fallbacks(fx, oracle, monkeypatch, d
     if dbg & 2: assert tm["vb_fallbacks"] > 0, "no frame was handed back: the fallback path was not exercised"
     else: assert tm["vb_repairs"] + tm["vb_fallbacks"] > 0, "no hand-over check failed: the repair path was not exercised"
     assert len(gf2) > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("grid", [1, 5, 64])
+def test_plan_kernels_any_number_of_workgroups(fx, oracle, monkeypatch, grid):
+    """fx_plan_kernel / fx_planlists_kernel lay the payload stage out with several workgroups over contiguous ranges of the
+    chain's frames: arena offsets by a decoupled look-back across workgroups, list slots by wave-aggregated counters.  Many
+    short frames of every modulation class and code class, several streams (some empty, some without a valid frame), any
+    grid -- including more workgroups than chunks of frames -- against the oracle."""
+    cases = [(2, 11, 40), (27, 15, 90), (1, 1, 16), (29, 20, 33), (3, 6, 64), (10, 17, 7), (18, 11, 0), (28, 27, 120), (9, 19, 55), (11, 11, 25)]
+    xs = [fx.synth_stream(180_000 + 7_000 * i, stream_id=950 + i, mod=m, fec0=f0, payload_len=pl, snr_db=30.0, gap=260 + 11 * i)[0] for i, (m, f0, pl) in enumerate(cases)]
+    xs.insert(3, np.zeros(50_000, np.complex64))                                  # a stream without any frame
+    rng = np.random.default_rng(5)
+    xs.append((0.3 * (rng.standard_normal(60_000) + 1j * rng.standard_normal(60_000))).astype(np.complex64))   # noise only
+    monkeypatch.setenv("FXRX_PLAN_GRID", str(grid))
+    ctx = fx.RxContext(len(xs), want_framesyms=True)
+    gf = ctx.process(xs)
+    n = 0
+    for s, x in enumerate(xs):
+        of = oracle_frames(oracle, x)
+        compare_frames(of, [g for g in gf if g["stream"] == s])
+        n += len(of)
+    assert n > 1500, n
+    # the same block again, pipelined with itself (hints, grids and arenas now come from the first pass)
+    ctx.reset(); ctx.set_depth(2)
+    ptrs = [x.ctypes.data for x in xs]; cnt = [len(x) for x in xs]
+    ctx.submit_raw(ptrs, cnt, False); ctx.reset(); ctx.submit_raw(ptrs, cnt, False)
+    a = ctx.results(ctx.collect_raw()); b = ctx.results(ctx.collect_raw())
+    key = lambda g: (g["stream"], g["start"], g["payload"], g["payload_valid"], g["evm_sum"])
+    assert [key(g) for g in a] == [key(g) for g in gf] == [key(g) for g in b]
+    ctx.close()
