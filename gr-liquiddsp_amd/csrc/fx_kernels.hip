@@ -3032,10 +3032,27 @@ __device__ __forceinline__ unsigned vb_retrace_block(const unsigned long long *d
 }
 
 // ---- front part, one wave per frame: symbols -> packet bytes, de-interleave, fec1 (not convolutional), de-interleave ----
+// The de-interleaver is four passes of dependent byte swaps: through global memory every one of its ~17 rounds per pass is
+// a memory round trip (the kernel took 113 us for 2-KB packets, nearly all of it waiting).  Packets that fit are therefore
+// packed and de-interleaved in LDS and written out once; longer ones take the same steps in place in global memory.
+#define VBPRE_LDS 12288
+__device__ __forceinline__ void vb_pack_bytes(const uint8_t *hs, unsigned bps, uint32_t nbytes, uint8_t *dst, int lane)
+{
+    for (uint32_t j = lane; j < nbytes; j += DEC_THREADS) {
+        unsigned v = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t k = 8 * j + b, sidx = k / bps, sb = bps - 1 - (k % bps);
+            v = (v << 1) | ((hs[sidx] >> sb) & 1u);
+        }
+        dst[j] = (uint8_t)v;
+    }
+}
 extern "C" __global__ __launch_bounds__(DEC_THREADS)
 void fx_vbpre_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr, uint32_t first_wave, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB,
                      const FxTables *T)
 {
+    __shared__ __attribute__((aligned(16))) uint8_t X[VBPRE_LDS];
     const uint32_t njobs = hdr->n_dec_batch;
     const uint32_t ji = first_wave + blockIdx.x;
     if (ji >= njobs) return;
@@ -3046,16 +3063,32 @@ void fx_vbpre_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBloc
     job.fec1 = __builtin_amdgcn_readfirstlane(job.fec1); job.bps = __builtin_amdgcn_readfirstlane(job.bps);
     uint8_t *A = bufA + job.byte_off, *B = bufB + job.byte_off;
     const uint8_t *hs = hard + job.sym_off;
-    const unsigned bps = job.bps;
-    for (uint32_t j = lane; j < job.l1; j += DEC_THREADS) {
-        unsigned v = 0;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint32_t k = 8 * j + b, sidx = k / bps, sb = bps - 1 - (k % bps);
-            v = (v << 1) | ((hs[sidx] >> sb) & 1u);
+    const bool in_lds = job.l1 + 32u <= VBPRE_LDS && job.l0 + 32u <= VBPRE_LDS;
+    if (in_lds) {
+        vb_pack_bytes(hs, job.bps, job.l1, X, lane);
+        __builtin_amdgcn_wave_barrier();
+        deinterleave_wave(X, job.l1, lane);
+        if (job.fec1 == FX_FEC_NONE) {
+            // (no outer code: the packet bytes are the inner code's already -- l0 = l1 -- and stay where they are)
+            deinterleave_wave(X, job.l0, lane);
+        } else {
+            for (uint32_t j = lane; j < job.l1; j += DEC_THREADS) A[j] = X[j];
+            __threadfence_block(); __builtin_amdgcn_wave_barrier();
+            block_fec_decode<false>(job.fec1, job.l0, A, B, T, lane);
+            __threadfence_block(); __builtin_amdgcn_wave_barrier();
+            for (uint32_t j = lane; j < job.l0; j += DEC_THREADS) X[j] = B[j];
+            __builtin_amdgcn_wave_barrier();
+            deinterleave_wave(X, job.l0, lane);
         }
-        A[j] = (uint8_t)v;
+        // out in 16-byte pieces (byte_off is a multiple of 16; the buffer has that much slack behind the packet), with the
+        // eight defined bytes behind the coded bits that the forward pass's window reads run into
+        if (lane < 16) X[job.l0 + lane] = 0;
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t n16 = (job.l0 + 8u + 15u) / 16u;
+        for (uint32_t j = lane; j < n16; j += DEC_THREADS) reinterpret_cast<uint4 *>(B)[j] = reinterpret_cast<const uint4 *>(X)[j];
+        return;
     }
+    vb_pack_bytes(hs, job.bps, job.l1, A, lane);
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     deinterleave_wave(A, job.l1, lane);
     block_fec_decode<false>(job.fec1, job.l0, A, B, T, lane);
