@@ -8,7 +8,7 @@ set -e
 R="$GRAFT_REPO_ROOT"; O="$R/gpurun_out/r02"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench_trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline > "$O/bench_under_rocprof.json" 2> "$O/bench_trace.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/bench_trace" -o bench -- python3 "$R/bench.py" --no-cpu-baseline --no-constellation > "$O/bench_under_rocprof.json" 2> "$O/bench_trace.err"
 echo "bench trace done"
 for c in 3 4 5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$O/cfg${c}_trace" -o cfg$c -- python3 "$R/tools/bench_configs.py" --only $c --passes 3 > "$O/cfg${c}_under_rocprof.json" 2> "$O/cfg${c}_trace.err"
