@@ -2403,10 +2403,24 @@ __device__ __forceinline__ void dec_tail(const FxPayJob &job, uint32_t jf, uint8
 // one frame, one wave.  SOFT: decoding from per-bit soft values (fx_softdemod_kernel wrote them, 8 per packet byte):
 // a convolutional stage decodes from soft values as long as nothing before it took hard decisions -- the stage nearest the
 // channel (fec1), and fec0 too when fec1 is FEC_NONE; every other stage takes hard decisions (value > 127).
+// de-interleave n bytes at buf through the wave's LDS buffer X when they fit (see fx_vbpre_kernel: the passes are dependent byte
+// swaps, slow through global memory), else in place
+#define DEC_LDS 12288
+__device__ __forceinline__ void deinterleave_staged(uint8_t *buf, uint32_t n, uint8_t *X, int lane)
+{
+    if (!X || n + 16u > DEC_LDS) { deinterleave_wave(buf, n, lane); return; }
+    const uint32_t n16 = (n + 15u) / 16u;                                       // (buffers are 16-byte aligned with slack behind the packet)
+    for (uint32_t j = lane; j < n16; j += DEC_THREADS) reinterpret_cast<uint4 *>(X)[j] = reinterpret_cast<const uint4 *>(buf)[j];
+    __builtin_amdgcn_wave_barrier();
+    deinterleave_wave(X, n, lane);
+    for (uint32_t j = lane; j < n16; j += DEC_THREADS) reinterpret_cast<uint4 *>(buf)[j] = reinterpret_cast<const uint4 *>(X)[j];
+    __threadfence_block(); __builtin_amdgcn_wave_barrier();
+}
+
 template <bool WITH_RS, bool SOFT>
 __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob *jobs, const uint32_t *job_idx, const uint8_t *hard, uint8_t *bufA,
                                           uint8_t *bufB, uint8_t *soft_arena, unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res,
-                                          const FxTables *T)
+                                          const FxTables *T, uint8_t *X)
 {
     const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
@@ -2445,7 +2459,7 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
                 block_fec_decode<WITH_RS>(job.fec0, job.k, B, A, T, lane);
             }
         } else {
-            deinterleave_wave(B, job.l0, lane);
+            deinterleave_staged(B, job.l0, X, lane);
             FX_STAMP(3);
             if (pc0 == 1) viterbi27<0>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
             else if (pc0) viterbi27<1>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
@@ -2467,7 +2481,7 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(0);
     // 2. outer plan (fec1): de-interleave l1 bytes in place, decode -> l0 bytes
-    deinterleave_wave(A, job.l1, lane);
+    deinterleave_staged(A, job.l1, X, lane);
     FX_STAMP(1);
     if (pc1 == 1) viterbi27<0>(1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
     else if (pc1) viterbi27<1>(pc1, job.l0, A, B, dw_arena + job.dw_off, A, lane, nullptr);
@@ -2475,7 +2489,7 @@ __device__ __forceinline__ void dec_frame(uint32_t ji, int lane, const FxPayJob 
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     FX_STAMP(2);
     // 3. inner plan (fec0): de-interleave l0 bytes in place, decode -> k bytes
-    deinterleave_wave(B, job.l0, lane);
+    deinterleave_staged(B, job.l0, X, lane);
     FX_STAMP(3);
     if (pc0 == 1) viterbi27<0>(1, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
     else if (pc0) viterbi27<1>(pc0, job.k, B, A, dw_arena + job.dw_off, B, lane, res ? &res[jf].stamp[6] : nullptr);
@@ -2498,6 +2512,8 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
     // plus a second, normally idle one for the rest -- and surplus waves leave at once.  The Reed-Solomon instance strides.
     // (fallback_host set: the list is that of the frames the batch Viterbi path handed back, and its length is passed on to
     // the host's copy of the header, for fxrx_collect to see whether this launch covered it)
+    __shared__ __attribute__((aligned(16))) uint8_t Xs[WITH_RS ? 16 : DEC_LDS];   // (the lean instance, one wave per workgroup: staging for the de-interleaver)
+    uint8_t *X = (!WITH_RS && blockDim.x == 64) ? Xs : nullptr;
     const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : (fallback_host ? hdr->n_vb_fallback : hdr->n_dec_plain);
     if (!WITH_RS && fallback_host && first_wave == 0 && blockIdx.x == 0 && threadIdx.x == 0) fallback_host->n_vb_fallback = njobs;
     const uint32_t wpg = blockDim.x >> 6;
@@ -2506,9 +2522,9 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
     if (ji0 >= njobs) return;
     __builtin_amdgcn_s_setprio(2);
     if constexpr (WITH_RS) {
-        for (uint32_t ji = ji0; ji < njobs; ji += gridDim.x * wpg) dec_frame<true, SOFT>(ji, lane, jobs, job_idx, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T);
+        for (uint32_t ji = ji0; ji < njobs; ji += gridDim.x * wpg) dec_frame<true, SOFT>(ji, lane, jobs, job_idx, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T, X);
     } else {
-        dec_frame<false, SOFT>(ji0, lane, jobs, job_idx, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T);
+        dec_frame<false, SOFT>(ji0, lane, jobs, job_idx, hard, bufA, bufB, soft_arena, dw_arena, out, recs, res, T, X);
     }
 }
 
