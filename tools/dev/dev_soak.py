@@ -8,7 +8,7 @@ fx = importlib.import_module("gr-liquiddsp_amd")
 import torch
 nblk = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 depth = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-x, inj = fx.synth_stream(6_000_000, stream_id=3)
+x, inj = fx.synth_stream(6_000_000, stream_id=3, snr_db=float(os.environ.get("SOAK_SNR", "20")))
 xd = torch.from_numpy(x).cuda()
 ptrs, counts = [xd.data_ptr()], [xd.numel()]
 key = lambda g: (g["start"], g["payload_valid"], hashlib.md5(g["payload"]).hexdigest(), g["evm_sum"], g["rxy"])
