@@ -188,7 +188,8 @@ struct FxBlockHdr {                      // device memory, zeroed at submit; mir
     uint32_t n_vb_items, vb_blk;         // its forward-pass work items (frame, trellis block) / trellis steps per block
     uint32_t vb_want;                    // work items the block's traffic asked for (those beyond the arena go the wave-per-frame way)
     uint32_t n_vb_fallback;              // frames the batch path could not verify: decoded again by the wave-per-frame decoder
-    uint32_t n_repair_req, pad0_;        // repair rounds: segments queued for a walk from their true start state
+    uint32_t n_repair_req;               // repair rounds: segments queued for a walk from their true start state
+    uint32_t runs_done;                  // verification runs emitted by the speculative walkers (verified before the true walkers start)
     uint32_t pll_cnt[FX_PLL_CLASSES];    // frames per modulation class
     uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
     uint64_t sym_total, byte_total, dw_total, out_total;

@@ -42,7 +42,7 @@
 extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
                                      FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total);
 extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results,
-                                           FxFrame *frames, FxBlockHdr *hdr, const FxTables *T);
+                                           FxFrame *frames, FxBlockHdr *hdr, const FxTables *T, uint32_t phase);
 extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
                                       FxWalkResult *results, FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxVerifyRun *runs, uint32_t run_cap,
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T);
@@ -193,6 +193,7 @@ struct fxrx_ctx_s {
     bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
+    hipStream_t st_chain = nullptr;      // highest priority: the state-dependent stretch of continuing blocks (true walkers, their verification, chain kernel)
     uint32_t plan_grid = 0;              // FXRX_PLAN_GRID: workgroups of the plan kernels (tests; default: from the last block's frame count)
     uint32_t vb_debug = 0, vb_blk_force = 0;   // tests: FXRX_VB_DEBUG (see fx_vbfix_kernel / fx_vbtrace_kernel), FXRX_VB_BLK (trellis steps per block)
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
@@ -288,7 +289,7 @@ static int make_slot(fxrx_ctx_s *c)
     return 0;
 }
 
-static void sync_all(fxrx_ctx_s *c) { for (auto &s : c->slots) if (s->st) (void)hipStreamSynchronize(s->st); }
+static void sync_all(fxrx_ctx_s *c) { if (c->st_chain) (void)hipStreamSynchronize(c->st_chain); for (auto &s : c->slots) if (s->st) (void)hipStreamSynchronize(s->st); }
 
 void fxrx_destroy(fxrx_ctx *c)
 {
@@ -299,6 +300,7 @@ void fxrx_destroy(fxrx_ctx *c)
         for (auto e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->st) (void)hipStreamDestroy(s->st);
     }
+    if (c->st_chain) { (void)hipStreamSynchronize(c->st_chain); (void)hipStreamDestroy(c->st_chain); }
     for (auto &S : c->st) for (auto &p : S.carry) if (p) (void)hipFree(p);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_state) (void)hipFree(c->d_state);
@@ -376,7 +378,7 @@ const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n)
 }
 
 enum { kChainFast = 0, kChainFull = 1, kChainDone = 2 };
-static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode);
+static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t chain_st = nullptr);
 
 // ---- enqueue the whole kernel chain of the block in `sl` (descriptors are rebuilt: a replay calls this again) ----
 static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
@@ -514,25 +516,45 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(sl.ev[0], st));
     HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
-    // the true walkers of continuing streams read the state the previous block's chain kernel leaves
+    // the true walkers of continuing streams read the state the previous block's chain kernel leaves.  What the speculative
+    // walkers skipped is verified before that wait -- it does not depend on the state --, so that the chain of dependencies
+    // from one block's chain kernel to the next one's is just: true walkers, their few verification runs, chain kernel
+    const bool verify = !detect && c->skip_seek && !sl.force_noskip;
+    hipStream_t cst = st;                                     // the stream the rest of the front part and the chain kernel go to
     if (!late.empty()) {
-        if (c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
-        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), st, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
+        if (verify) {
+            HIP_OK(hipMemcpyAsync(&sl.d_hdr.p->runs_done, &sl.d_hdr.p->n_runs, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            HIP_OK(fx_launch_seekverify(4u * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 0u));
+        }
+        // (from here to the chain kernel the block is on the chain of dependencies that runs through all blocks of a continuing
+        // stream: a single workgroup or two that must not queue behind the chip-filling kernels of the other blocks in flight
+        // -- so this stretch goes to the context's high-priority stream, which also keeps the chain kernels in block order)
+        if (!c->st_chain) {
+            int lo = 0, hi = 0;
+            HIP_OK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_OK(hipStreamCreateWithPriority(&c->st_chain, hipStreamNonBlocking, hi));
+        }
+        HIP_OK(hipEventRecord(sl.ev[9], st));
+        cst = c->st_chain;
+        HIP_OK(hipStreamWaitEvent(cst, sl.ev[9], 0));
+        if (c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), cst, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
     }
-    HIP_OK(hipEventRecord(sl.ev[1], st));
-    if (!detect && c->skip_seek && !sl.force_noskip)
-        HIP_OK(fx_launch_seekverify(4u * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables));
-    HIP_OK(hipEventRecord(sl.ev[2], st));
+    HIP_OK(hipEventRecord(sl.ev[1], cst));
+    if (verify)
+        HIP_OK(fx_launch_seekverify(late.empty() ? 4u * (unsigned)c->n_cus : (unsigned)std::min<size_t>(4u * (size_t)c->n_cus, std::max<size_t>(64, 16 * late.size())), cst, sl.d_runs.p,
+                                    sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 1u));
+    HIP_OK(hipEventRecord(sl.ev[2], cst));
     // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
     // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
-    if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(st, c->prev_chain, 0));
-    if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(st, c->carry_reader[(b + 1) % 3], 0));
-    return enqueue_back(c, sl, kChainFast);
+    if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
+    if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(cst, c->carry_reader[(b + 1) % 3], 0));
+    return enqueue_back(c, sl, kChainFast, cst);
 }
 
 // ---- back part of the chain: chain kernel, plan, payload stage.  `full`: the full-size chain kernel, which can walk
 // (fxrx_collect runs it for a block whose lean chain kernel reported FX_BLK_NEEDS_REPAIR) ----
-static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
+static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t chain_st)
 {
     const unsigned NS = c->cfg.n_streams;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
@@ -547,9 +569,10 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode)
         HIP_OK(fx_launch_chain(mode, c->cfg.equalizer ? 1 : 0, NS, st, d_streams, d_jobs, (uint32_t)sl.NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
                                hdr, c->chain_slow ? 1u : 0u, c->d_tables));
     else if (chain_mode == kChainFast)
-        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u, nullptr, nullptr));
+        HIP_OK(fx_launch_chainfast(NS, chain_st ? chain_st : st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u, nullptr, nullptr));
     // (kChainDone: the repair rounds have stitched the block already)
-    HIP_OK(hipEventRecord(sl.ev[3], st));
+    HIP_OK(hipEventRecord(sl.ev[3], chain_mode == kChainFast && chain_st ? chain_st : st));
+    if (chain_mode == kChainFast && chain_st && chain_st != st) HIP_OK(hipStreamWaitEvent(st, sl.ev[3], 0));   // back onto the block's own stream
     c->prev_chain = sl.ev[3];
     // (the plan kernels' workgroups take contiguous ranges of the chain's frames: about 2048 each, from the last block's count)
     HIP_OK(fx_launch_plan(st, c->plan_grid ? c->plan_grid : (unsigned)std::min<uint64_t>(64, c->frames_hint / 2048 + 1), d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p,

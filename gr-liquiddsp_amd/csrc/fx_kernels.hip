@@ -840,12 +840,15 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipS
 template <int WW>
 __global__ __launch_bounds__(64 * WW, FX_DETECT_OCC)
 void fx_seekverify_kernel(const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, FxBlockHdr *hdr,
-                          const FxTables *T)
+                          const FxTables *T, uint32_t phase)
 {
+    // phase 0: the runs [0, runs_done) -- those of the speculative walkers of a block of continuing streams, verified while
+    // the block still waits for its predecessor's state; phase 1: the rest (runs_done is 0 when the block has no such wait)
     constexpr int WALK_THREADS = 64 * WW;
     __shared__ SeekLdsT<WW> L;
-    const uint32_t nruns = min(hdr->n_runs, run_cap);
-    if (blockIdx.x >= nruns) return;
+    const uint32_t split = min(hdr->runs_done, run_cap);
+    const uint32_t run0 = phase ? split : 0u, nruns = phase ? min(hdr->n_runs, run_cap) : split;
+    if (run0 + blockIdx.x >= nruns) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float2 twA[7], twB[7];
 #pragma unroll
@@ -853,7 +856,7 @@ void fx_seekverify_kernel(const FxVerifyRun *runs, uint32_t run_cap, const FxWal
     for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
     const float s2sum = T->s2sum;
     const bool lo = tid < HALF;
-    for (uint32_t ri = blockIdx.x; ri < nruns; ri += gridDim.x) {
+    for (uint32_t ri = run0 + blockIdx.x; ri < nruns; ri += gridDim.x) {
         const FxVerifyRun run = runs[ri];
         const FxWalkJob &jb = jobs[run.job];
         const XSrc xs = { jb.x, jb.xa_end, jb.n };
@@ -884,10 +887,10 @@ void fx_seekverify_kernel(const FxVerifyRun *runs, uint32_t run_cap, const FxWal
 }
 
 extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results,
-                                           FxFrame *frames, FxBlockHdr *hdr, const FxTables *T)
+                                           FxFrame *frames, FxBlockHdr *hdr, const FxTables *T, uint32_t phase)
 {
     if (grid == 0) return hipSuccess;
-    hipLaunchKernelGGL(fx_seekverify_kernel<FX_VERIFY_WAVES>, dim3(grid), dim3(64 * FX_VERIFY_WAVES), 0, st, runs, run_cap, jobs, results, frames, hdr, T);
+    hipLaunchKernelGGL(fx_seekverify_kernel<FX_VERIFY_WAVES>, dim3(grid), dim3(64 * FX_VERIFY_WAVES), 0, st, runs, run_cap, jobs, results, frames, hdr, T, phase);
     return hipGetLastError();
 }
 
