@@ -68,6 +68,7 @@ extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_w
 extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wave, unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs,
                                        const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, uint8_t *soft_arena,
                                        unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T, FxBlockHdr *fallback_host);
+extern "C" hipError_t fx_launch_symcopy(unsigned grid, hipStream_t st, const FxBlockHdr *hdr, const float2 *sym, float2 *host);
 extern "C" hipError_t fx_launch_softdemod(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                           const float2 *framesyms, const uint8_t *hard, uint8_t *soft_arena, const FxTables *T);
 
@@ -630,9 +631,9 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
                                     sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
         } else sl.vb_pre_launched = sl.vb_items_launched = sl.fb_launched = 0;
         HIP_OK(hipEventRecord(sl.ev[7], st));
-        // (the copy's length is the arena's upper bound: how many symbols the block really holds is only known on the device)
+        // (a copy kernel: it knows how many symbols the block really holds)
         if (c->cfg.want_framesyms)
-            HIP_OK(hipMemcpyAsync(sl.h_framesyms.p, sl.d_symraw.p, sl.sym_cap * sizeof(float2), hipMemcpyDeviceToHost, st));
+            HIP_OK(fx_launch_symcopy(2u * (unsigned)c->n_cus, st, hdr_pay, sl.d_symraw.p, sl.h_framesyms.p));
     } else {
         HIP_OK(hipEventRecord(sl.ev[5], st)); HIP_OK(hipEventRecord(sl.ev[6], st)); HIP_OK(hipEventRecord(sl.ev[7], st));
         c->carry_reader[b % 3] = sl.ev[5];

@@ -3189,6 +3189,21 @@ extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, 
     return hipGetLastError();
 }
 
+// ---- payload symbols to the host (fxrx_config.want_framesyms): as many as the block holds -- a count only the device knows,
+// where a hipMemcpyAsync would have to move the arena's upper bound -- in 16-byte stores straight into pinned host memory
+extern "C" __global__ __launch_bounds__(256)
+void fx_symcopy_kernel(const FxBlockHdr *hdr, const float2 *sym, float2 *host)
+{
+    const size_t n16 = ((size_t)hdr->sym_total * sizeof(float2) + 15) / 16;
+    const uint4 *src = reinterpret_cast<const uint4 *>(sym); uint4 *dst = reinterpret_cast<uint4 *>(host);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+extern "C" hipError_t fx_launch_symcopy(unsigned grid, hipStream_t st, const FxBlockHdr *hdr, const float2 *sym, float2 *host)
+{
+    hipLaunchKernelGGL(fx_symcopy_kernel, dim3(grid), dim3(256), 0, st, hdr, sym, host);
+    return hipGetLastError();
+}
+
 // ===================================================================== payload: soft decisions (optional)
 // One thread per payload symbol: the carrier-recovered symbol (fx_paypll_kernel left it in framesyms) -> bps soft values,
 // 0 = surely 0 ... 255 = surely 1, MSB of the symbol first, written at the bit's position in the packet (8 soft values per
