@@ -377,9 +377,13 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
                     pos += (int64_t)FX_HOP * hw; fresh = false;
                 }
             } else if (hw >= 0) {
+                // candidate preamble at p: the exact detector takes over on the hop whose new half starts at p, behind a
+                // synchroniser reset at p - 256 (the hop before it -- zeros and x[p-256, p) -- cannot hold the preamble)
                 const int64_t p = pos - FX_HOP + (int64_t)FX_HOP * hw + (int64_t)L.cand[hw];
-                pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
-                if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
+                pos = p; floor_ = p - FX_HOP; fresh = false; exact_left = 2;
+                const float2 w = lo ? xv(xs, pos - FX_HOP + tid, floor_) : make_float2(0.0f, 0.0f);
+                if (lo) L.win[tid] = w;
+                x2_0 = block_sum256(cm2(w), L, lane, wave);
             } else {
                 const float2 w = lo ? L.cw[WALK_WAVES * FX_HOP + tid] : make_float2(0.0f, 0.0f);
                 if (lo) L.win[tid] = w;                                  // last hop becomes the overlap half
@@ -438,10 +442,13 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
             if (cpk > 0.06f * ed * T->td2sum * (float)FX_NFFT * (float)FX_NFFT && ed > 0.0f) {
                 if (locked) { coarse_hit = true; exact_left = 3; hops_cheap--; }   // run the exact detector on this very hop
                 else {
-                    // candidate preamble at p: restart the exact detector, fresh, one hop earlier
+                    // candidate preamble at p: the exact detector takes over on the hop whose new half starts at p (see above)
                     const int64_t p = pos - FX_HOP + (int64_t)cl;
-                    pos = p - FX_HOP; floor_ = pos; fresh = true; x2_0 = 0.0f; exact_left = 3;
-                    if (lo) L.win[tid] = make_float2(0.0f, 0.0f);
+                    pos = p; floor_ = p - FX_HOP; fresh = false; exact_left = 2;
+                    __syncthreads();
+                    const float2 w = lo ? xv(xs, pos - FX_HOP + tid, floor_) : make_float2(0.0f, 0.0f);
+                    if (lo) L.win[tid] = w;
+                    x2_0 = block_sum256(cm2(w), L, lane, wave);
                     __syncthreads();
                     continue;
                 }
