@@ -488,7 +488,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     sl.o_list = o_list; sl.o_streams = o_streams;
     const uint32_t list_cap = chain_slots + 64 * FX_PLL_CLASSES;
     if (sl.hp_desc.reserve(desc_bytes) || sl.d_desc.reserve(desc_bytes) || sl.d_wres.reserve(NJ + NS) || sl.d_frames.reserve(frame_slots) ||
-        sl.d_runs.reserve(sl.run_cap) || sl.d_req.reserve(NJ) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
+        sl.d_runs.reserve(sl.run_cap) || sl.d_req.reserve(2 * NJ + 16) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
         sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(4 * (size_t)list_cap)) return FXRX_ERR_HIP;
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
@@ -715,7 +715,7 @@ static int repair_rounds(fxrx_ctx_s *c, Slot &sl)
         HIP_OK(hipStreamSynchronize(st));
         if (std::getenv("FXRX_DEBUG_ROUNDS")) std::fprintf(stderr, "[fxrx] repair round %d: flags %x requests %u\n", round, hh.flags, hh.n_repair_req);
         if (!(hh.flags & FX_BLK_NEEDS_REPAIR)) return 0;          // (hdr keeps what the chain kernel left there -- flags, stamps -- for the plan kernel)
-        if ((hh.flags & FX_BLK_NEEDS_SLOW) || hh.n_repair_req == 0 || hh.n_repair_req > sl.NJ) break;
+        if ((hh.flags & FX_BLK_NEEDS_SLOW) || hh.n_repair_req == 0 || hh.n_repair_req > 2 * sl.NJ) break;   // (a segment is queued at most twice: as a miss target and for a fired hop)
         {   // streams in which a skipped hop fired: their next blocks are walked with the exact detector on every hop from the start
             std::vector<uint32_t> req(hh.n_repair_req);
             HIP_OK(hipMemcpyAsync(req.data(), sl.d_req.p, req.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
