@@ -37,7 +37,7 @@ class Stats(C.Structure):
 
 
 class FrameInfo(C.Structure):
-    _fields_ = [("start", C.c_uint64), ("offset", C.c_int), ("rxy", C.c_float), ("tau", C.c_float),
+    _fields_ = [("start", C.c_int64), ("offset", C.c_int), ("rxy", C.c_float), ("tau", C.c_float),
                 ("gamma", C.c_float), ("dphi", C.c_float), ("phi", C.c_float),
                 ("pfb_index", C.c_uint), ("mf_counter0", C.c_int),
                 ("pilot_dphi", C.c_float), ("pilot_phi", C.c_float), ("pilot_gain", C.c_float),
