@@ -37,8 +37,9 @@ def _run(fx, oracle, iters, seed, verbose):
                    FXRX_SKIP_SEEK=str(rng.choice([1, 1, 0])))
         os.environ.update(env)
         seg = int(rng.choice([0, 8192, 50_000])); depth = int(rng.choice([1, 3])); ncut = int(rng.choice([1, 1, 3]))
-        ofs = [oracle_frames(oracle, x) for x in xs]
-        ctx = fx.RxContext(ns, want_framesyms=True, segment_len=seg); ctx.set_depth(depth)
+        eq = bool(rng.random() < 0.15); soft = bool(rng.random() < 0.15)            # the optional stages, now and then
+        ofs = [oracle_frames(oracle, x, equalizer=eq, soft=soft) for x in xs]
+        ctx = fx.RxContext(ns, want_framesyms=True, segment_len=seg, equalizer=eq, soft_decision=soft); ctx.set_depth(depth)
         got, inflight = [], 0
         cuts = [[len(x) * k // ncut for k in range(ncut + 1)] for x in xs]
         keep = []
@@ -54,7 +55,7 @@ def _run(fx, oracle, iters, seed, verbose):
                 compare_frames(ofs[s], mine)
                 nframes += len(ofs[s]); nbad_payload += sum(1 for f in ofs[s] if f.header_valid and not f.payload_valid)
         except AssertionError as e:
-            raise AssertionError("fuzz iteration %d (seed %d): streams %s env %s seg %d depth %d cuts %d -> %s" % (it, seed, desc, env, seg, depth, ncut, e))
+            raise AssertionError("fuzz iteration %d (seed %d): streams %s env %s seg %d depth %d cuts %d eq %d soft %d -> %s" % (it, seed, desc, env, seg, depth, ncut, eq, soft, e))
         if verbose:
-            print("it %d ok: %d streams, env %s seg %d depth %d cuts %d, repairs %d vb_repairs %d fallbacks %d" % (it, ns, env, seg, depth, ncut, tm["repairs"], tm["vb_repairs"], tm["vb_fallbacks"]), flush=True)
+            print("it %d ok: %d streams, env %s seg %d depth %d cuts %d eq %d soft %d, repairs %d vb_repairs %d fallbacks %d" % (it, ns, env, seg, depth, ncut, eq, soft, tm["repairs"], tm["vb_repairs"], tm["vb_fallbacks"]), flush=True)
     return nframes, nbad_payload
