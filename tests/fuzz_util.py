@@ -38,6 +38,24 @@ def _run(fx, oracle, iters, seed, verbose):
         os.environ.update(env)
         seg = int(rng.choice([0, 8192, 50_000])); depth = int(rng.choice([1, 3])); ncut = int(rng.choice([1, 1, 3]))
         eq = bool(rng.random() < 0.15); soft = bool(rng.random() < 0.15)            # the optional stages, now and then
+        if rng.random() < 0.12:                                                      # ... and the detector-only mode (frame_detector_cc)
+            ctx = fx.RxContext(ns, mode=fx.MODE_DETECTOR, threshold=0.45, segment_len=seg); ctx.set_depth(depth)
+            got, inflight, keep = [], 0, []
+            cuts = [[len(x) * k // ncut for k in range(ncut + 1)] for x in xs]
+            for k in range(ncut):
+                parts = [np.ascontiguousarray(x[c[k]:c[k + 1]]) for x, c in zip(xs, cuts)]; keep.append(parts)
+                if inflight == depth: got += ctx.results(ctx.collect_raw()); inflight -= 1
+                ctx.submit_raw([p.ctypes.data for p in parts], [len(p) for p in parts], False); inflight += 1
+            while inflight: got += ctx.results(ctx.collect_raw()); inflight -= 1
+            ctx.close()
+            for s_, x in enumerate(xs):
+                want = [d["pos"] for d in oracle.Detector(0.45).run(x) if d["pos"] + 512 <= len(x)]
+                mine = [g["start"] for g in got if g["stream"] == s_]
+                if mine[:len(want)] != want:
+                    raise AssertionError("fuzz iteration %d (seed %d), detector mode: stream %d %s seg %d depth %d cuts %d: %d vs %d detections" % (it, seed, s_, desc[s_], seg, depth, ncut, len(mine), len(want)))
+                nframes += len(want)
+            if verbose: print("it %d ok: detector mode, %d streams seg %d depth %d cuts %d" % (it, ns, seg, depth, ncut), flush=True)
+            continue
         ofs = [oracle_frames(oracle, x, equalizer=eq, soft=soft) for x in xs]
         ctx = fx.RxContext(ns, want_framesyms=True, segment_len=seg, equalizer=eq, soft_decision=soft); ctx.set_depth(depth)
         got, inflight = [], 0
