@@ -249,7 +249,9 @@ int upload_tables(fxrx_ctx_s *c)
 
 // frame-table slots per walk job: the densest legal traffic is a header-only frame (618 samples) after the other.  (Should a
 // table fill up all the same -- FX_EXIT_TABLE_FULL -- the full-size chain kernel continues the segment.)
-inline uint32_t seg_frames_cap(uint64_t seg) { return (uint32_t)std::min<uint64_t>(seg / 600 + 8, 4000); }
+// Densest possible traffic: a flexframe is at least ~630 samples long (preamble, header, tail), so flex_rx finds at most one frame
+// per 600 samples; the bare detector (frame_detector_cc) can fire again on the very next hop, 256 samples on.
+inline uint32_t seg_frames_cap(uint64_t seg, bool detect) { return (uint32_t)std::min<uint64_t>(seg / (detect ? 256 : 600) + 8, 4000); }
 
 int alloc_carry(StreamState &S, int64_t cap)
 {
@@ -435,7 +437,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
             j.mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
             j.handoff = j.stop < ns ? 1u : 0u;
             j.prelock = first ? 0u : 1u;
-            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && cont ? (uint64_t)sn.carry_bound : 0u));
+            j.frame_base = frame_slots; j.max_frames = seg_frames_cap((uint64_t)(j.stop - j.start) + (first && cont ? (uint64_t)sn.carry_bound : 0u), detect);
             frame_slots += j.max_frames;
             j.threshold = c->cfg.threshold;
             j.no_skip = (detect || !c->skip_seek || sl.force_noskip || sn.noskip) ? 1u : 0u;
@@ -447,7 +449,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
             if (p >= ns) break;
         }
         sd.n_jobs = (uint32_t)jobs.size() - sd.first_job;
-        sd.chain_base = chain_slots; sd.chain_cap = (uint32_t)((uint64_t)(ns + (cont ? sn.carry_bound : 0)) / 600u + 8u);
+        sd.chain_base = chain_slots; sd.chain_cap = (uint32_t)((uint64_t)(ns + (cont ? sn.carry_bound : 0)) / (detect ? 256u : 600u) + 8u);
         chain_slots += sd.chain_cap;
         n_total += (uint64_t)ns; carry_total += cont ? (uint64_t)sn.carry_bound : 0u;
     }
@@ -802,6 +804,7 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
         break;
     }
     if (sl.h_hdr.p->flags & (FX_BLK_NEEDS_REPAIR | FX_BLK_CARRY_OVERFLOW)) { set_err("fxrx_collect: block could not be repaired"); return FXRX_ERR_STATE; }
+    if (sl.h_hdr.p->flags & FX_BLK_CHAIN_FULL) { set_err("fxrx_collect: chain table overflow (internal sizing error)"); return FXRX_ERR_STATE; }
     // the blocks behind it, oldest first (descriptors are rebuilt: carry buffers may have moved)
     c->prev_chain = sl.ev[3];
     const unsigned n_replay = carry_moved ? c->inflight - 1 : n_dep;

@@ -3064,12 +3064,14 @@ __device__ __forceinline__ unsigned vb_retrace_block(const unsigned long long *d
 #define VBPRE_LDS 12288
 __device__ __forceinline__ void vb_pack_bytes(const uint8_t *hs, unsigned bps, uint32_t nbytes, uint8_t *dst, int lane)
 {
+    // (bit 8 j of the packet is bit bps - 1 - (8 j mod bps) of symbol 8 j / bps: one division per byte, then the bits are walked)
     for (uint32_t j = lane; j < nbytes; j += DEC_THREADS) {
-        unsigned v = 0;
+        uint32_t sidx = (8u * j) / bps; int sb = (int)(bps - 1u - (8u * j - sidx * bps));
+        unsigned v = 0, cur = hs[sidx];
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            const uint32_t k = 8 * j + b, sidx = k / bps, sb = bps - 1 - (k % bps);
-            v = (v << 1) | ((hs[sidx] >> sb) & 1u);
+            v = (v << 1) | ((cur >> sb) & 1u);
+            if (--sb < 0 && b < 7) { sb = (int)bps - 1; cur = hs[++sidx]; }
         }
         dst[j] = (uint8_t)v;
     }

@@ -31,8 +31,9 @@ def _run(fx, oracle, iters, seed, verbose):
             if rng.random() < 0.5: f1 = 1                                   # most traffic has no outer code
             pl = int(rng.choice([0, 1, 7, 16, 100, 333, 1024, 2000])); gap = int(rng.choice([0, 64, 256, 300, 1500]))
             snr = float(rng.choice([3.0, 5.0, 8.0, 12.0, 20.0, 30.0])); n = int(rng.integers(60_000, 400_000))
-            xs.append(fx.synth_stream(n, stream_id=int(rng.integers(1 << 20)), mod=m, fec0=f0, fec1=f1, payload_len=pl, gap=gap, snr_db=snr)[0])
-            desc.append((m, f0, f1, pl, gap, snr, n))
+            sid = int(rng.integers(1 << 20))
+            xs.append(fx.synth_stream(n, stream_id=sid, mod=m, fec0=f0, fec1=f1, payload_len=pl, gap=gap, snr_db=snr)[0])
+            desc.append((m, f0, f1, pl, gap, snr, n, sid))
         env = dict(FXRX_VB_BLK=str(rng.choice([0, 128, 192, 448])), FXRX_PLAN_GRID=str(rng.choice([0, 3])), FXRX_VB_DEBUG=str(rng.choice([0, 0, 1, 2])),
                    FXRX_SKIP_SEEK=str(rng.choice([1, 1, 0])))
         os.environ.update(env)
@@ -52,7 +53,9 @@ def _run(fx, oracle, iters, seed, verbose):
                 want = [d["pos"] for d in oracle.Detector(0.45).run(x) if d["pos"] + 512 <= len(x)]
                 mine = [g["start"] for g in got if g["stream"] == s_]
                 if mine[:len(want)] != want:
-                    raise AssertionError("fuzz iteration %d (seed %d), detector mode: stream %d %s seg %d depth %d cuts %d: %d vs %d detections" % (it, seed, s_, desc[s_], seg, depth, ncut, len(mine), len(want)))
+                    k = next((i for i, (a, b) in enumerate(zip(mine, want)) if a != b), min(len(mine), len(want)))
+                    raise AssertionError("fuzz iteration %d (seed %d), detector mode: stream %d %s seg %d depth %d cuts %d: %d vs %d detections, first difference at #%d: gpu %s oracle %s (len %d)"
+                                         % (it, seed, s_, desc[s_], seg, depth, ncut, len(mine), len(want), k, mine[max(0, k - 2):k + 3], want[max(0, k - 2):k + 3], len(x)))
                 nframes += len(want)
             if verbose: print("it %d ok: detector mode, %d streams seg %d depth %d cuts %d" % (it, ns, seg, depth, ncut), flush=True)
             continue

@@ -799,3 +799,18 @@ def test_plan_kernels_any_number_of_workgroups(fx, oracle, monkeypatch, grid):
     key = lambda g: (g["stream"], g["start"], g["payload"], g["payload_valid"], g["evm_sum"])
     assert [key(g) for g in a] == [key(g) for g in gf] == [key(g) for g in b]
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_detector_mode_dense_detections_fit_the_tables(fx, oracle):
+    """frame_detector_cc on dense traffic of tiny frames: the bare detector fires more often than once per 600 samples (the
+    densest flex_rx can see) -- tables are sized for one detection per 256-sample hop in this mode.  (Found by the randomised
+    test: results used to be cut off silently at samples / 600 + 8 detections per stream.)"""
+    x = fx.synth_stream(126492, stream_id=313177, mod=28, fec0=18, fec1=7, payload_len=7, gap=300, snr_db=30.0)[0]
+    want = [d["pos"] for d in oracle.Detector(0.45).run(x) if d["pos"] + 512 <= len(x)]
+    assert len(want) > len(x) // 600 + 8
+    for seg in (0, 8192):
+        ctx = fx.RxContext(1, mode=fx.MODE_DETECTOR, threshold=0.45, segment_len=seg)
+        mine = [g["start"] for g in ctx.process([x])]
+        ctx.close()
+        assert mine[:len(want)] == want
