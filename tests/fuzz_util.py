@@ -64,10 +64,15 @@ def _run(fx, oracle, iters, seed, verbose):
         got, inflight = [], 0
         cuts = [[len(x) * k // ncut for k in range(ncut + 1)] for x in xs]
         keep = []
+        on_dev = bool(rng.random() < 0.25)                                       # inputs already in device memory (used in place)
         for k in range(ncut):
-            parts = [np.ascontiguousarray(x[c[k]:c[k + 1]]) for x, c in zip(xs, cuts)]; keep.append(parts)
+            parts = [np.ascontiguousarray(x[c[k]:c[k + 1]]) for x, c in zip(xs, cuts)]
+            if on_dev:
+                import torch
+                parts = [torch.from_numpy(p).cuda() for p in parts]
+            keep.append(parts)
             if inflight == depth: got += ctx.results(ctx.collect_raw()); inflight -= 1
-            ctx.submit_raw([p.ctypes.data for p in parts], [len(p) for p in parts], False); inflight += 1
+            ctx.submit_raw([p.data_ptr() if on_dev else p.ctypes.data for p in parts], [len(p) for p in parts], on_dev); inflight += 1
         while inflight: got += ctx.results(ctx.collect_raw()); inflight -= 1
         tm = ctx.timing(); ctx.close()
         try:
