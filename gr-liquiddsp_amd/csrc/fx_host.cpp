@@ -195,6 +195,8 @@ struct fxrx_ctx_s {
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
     hipStream_t st_chain = nullptr;      // highest priority: the state-dependent stretch of continuing blocks (true walkers, their verification, chain kernel)
+    uint32_t mf_per_cu = 0;              // FXRX_MF_PER_CU: workgroups of the payload matched filter per CU (0: one per item of the last block)
+    uint64_t mf_items_hint = 0;
     uint32_t plan_grid = 0;              // FXRX_PLAN_GRID: workgroups of the plan kernels (tests; default: from the last block's frame count)
     uint32_t vb_debug = 0, vb_blk_force = 0;   // tests: FXRX_VB_DEBUG (see fx_vbfix_kernel / fx_vbtrace_kernel), FXRX_VB_BLK (trellis steps per block)
     // pipeline: a ring of depth + 1 slots, so that the block whose results are exposed is never the one being refilled
@@ -329,6 +331,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_MF_PER_CU")) c->mf_per_cu = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_PLAN_GRID")) c->plan_grid = (uint32_t)std::min(256, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VB_DEBUG")) c->vb_debug = (uint32_t)std::atoi(e);
     // (a block is at least as long as the warm-up of the next one: 128 steps)
@@ -585,7 +588,10 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
     if (!detect) {
         // grids stride over lists whose lengths only the device knows; size them from what the last block held
         const uint64_t fh = c->frames_hint ? std::min<uint64_t>(chain_slots, c->frames_hint + c->frames_hint / 2 + 64) : chain_slots;
-        const unsigned mf_grid = (unsigned)std::min<uint64_t>(sl.mf_cap, 8ull * (uint64_t)c->n_cus);
+        // (one workgroup per item of 1024 symbols when the previous block's count is anything to go by -- measured better than
+        // fewer workgroups striding over the items: 8 per CU 34.3, 18: 35.1, one per item (36 per CU on config 2): 35.3 Gsamples/s)
+        const unsigned mf_grid = (unsigned)std::min<uint64_t>(sl.mf_cap, c->mf_per_cu ? (uint64_t)c->mf_per_cu * (uint64_t)c->n_cus
+                                                                                     : std::max<uint64_t>(8ull * (uint64_t)c->n_cus, c->mf_items_hint + c->mf_items_hint / 8 + 64));
         HIP_OK(fx_launch_paymf(mf_grid, c->cfg.equalizer ? 1 : 0, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_chain.p, sl.d_symraw.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[5], st));
         c->carry_reader[b % 3] = sl.ev[5];
@@ -919,7 +925,7 @@ int fxrx_collect(fxrx_ctx *c)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
     c->frames_hint = h.n_frames; c->plain_hint = h.n_dec_plain; c->batch_hint = h.n_dec_batch; c->vb_items_hint = h.n_vb_items;
-    c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
+    c->mf_items_hint = h.n_mfblk; c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
     c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - c->rs_hint / 8;      // (fades out over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
