@@ -195,6 +195,7 @@ struct fxrx_ctx_s {
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
     hipStream_t st_chain = nullptr;      // highest priority: the state-dependent stretch of continuing blocks (true walkers, their verification, chain kernel)
+    uint32_t verify_per_cu = 4;          // FXRX_VERIFY_PER_CU: workgroups of the seek verifier per CU (they stride over the runs)
     uint32_t mf_per_cu = 0;              // FXRX_MF_PER_CU: workgroups of the payload matched filter per CU (0: one per item of the last block)
     uint64_t mf_items_hint = 0;
     uint32_t plan_grid = 0;              // FXRX_PLAN_GRID: workgroups of the plan kernels (tests; default: from the last block's frame count)
@@ -331,6 +332,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_VERIFY_PER_CU")) c->verify_per_cu = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_MF_PER_CU")) c->mf_per_cu = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_PLAN_GRID")) c->plan_grid = (uint32_t)std::min(256, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VB_DEBUG")) c->vb_debug = (uint32_t)std::atoi(e);
@@ -530,7 +532,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (!late.empty()) {
         if (verify) {
             HIP_OK(hipMemcpyAsync(&sl.d_hdr.p->runs_done, &sl.d_hdr.p->n_runs, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-            HIP_OK(fx_launch_seekverify(4u * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 0u));
+            HIP_OK(fx_launch_seekverify(c->verify_per_cu * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 0u));
         }
         // (from here to the chain kernel the block is on the chain of dependencies that runs through all blocks of a continuing
         // stream: a single workgroup or two that must not queue behind the chip-filling kernels of the other blocks in flight
@@ -548,7 +550,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     }
     HIP_OK(hipEventRecord(sl.ev[1], cst));
     if (verify)
-        HIP_OK(fx_launch_seekverify(late.empty() ? 4u * (unsigned)c->n_cus : (unsigned)std::min<size_t>(4u * (size_t)c->n_cus, std::max<size_t>(64, 16 * late.size())), cst, sl.d_runs.p,
+        HIP_OK(fx_launch_seekverify(late.empty() ? c->verify_per_cu * (unsigned)c->n_cus : (unsigned)std::min<size_t>((size_t)c->verify_per_cu * (size_t)c->n_cus, std::max<size_t>(64, 16 * late.size())), cst, sl.d_runs.p,
                                     sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 1u));
     HIP_OK(hipEventRecord(sl.ev[2], cst));
     // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
