@@ -3061,7 +3061,7 @@ __device__ __forceinline__ unsigned vb_retrace_block(const unsigned long long *d
 // The de-interleaver is four passes of dependent byte swaps: through global memory every one of its ~17 rounds per pass is
 // a memory round trip (the kernel took 113 us for 2-KB packets, nearly all of it waiting).  Packets that fit are therefore
 // packed and de-interleaved in LDS and written out once; longer ones take the same steps in place in global memory.
-#define VBPRE_LDS 12288
+#define VBPRE_LDS 4608           // (packets up to ~4.5 KB -- 2 KB payloads at rate 1/2 -- stay in LDS; at 12 KB a CU held only 13 of these one-wave workgroups)
 __device__ __forceinline__ void vb_pack_bytes(const uint8_t *hs, unsigned bps, uint32_t nbytes, uint8_t *dst, int lane)
 {
     // (bit 8 j of the packet is bit bps - 1 - (8 j mod bps) of symbol 8 j / bps: one division per byte, then the bits are walked)

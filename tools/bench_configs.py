@@ -42,9 +42,14 @@ def run(fx, torch, name, n_streams, n_samples, gen, mode, passes, distinct=16, p
                     n_bytes_ok += int(g["payload_valid"] and g["payload"] == pl)
     ok = n_bytes_ok == n_inj
     torch.cuda.synchronize(); t0 = time.perf_counter()
+    per_pass = []
     for _ in range(passes):
+        t1 = time.perf_counter()
         ctx.reset(); ctx.process_raw(ptrs, counts, True)
+        if os.environ.get("BENCH_CONFIGS_DEBUG"):
+            t_ = ctx.timing(); per_pass.append((round((time.perf_counter() - t1) * 1e3, 2), t_["replays"], t_["late_decodes"], t_["repairs"], round(t_["host_submit_ms"], 2), round(t_["total_ms"], 2)))
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / passes
+    if per_pass: print("per pass (ms, replays, late_decodes, repairs, submit ms, kernels ms):", per_pass, file=sys.stderr, flush=True)
     tm = ctx.timing()
     # the same passes with several in flight (each pass is an independent capture of all streams: reset in between)
     depth = 4
