@@ -2415,7 +2415,7 @@ __device__ __forceinline__ void dec_tail(const FxPayJob &job, uint32_t jf, uint8
 // channel (fec1), and fec0 too when fec1 is FEC_NONE; every other stage takes hard decisions (value > 127).
 // de-interleave n bytes at buf through the wave's LDS buffer X when they fit (see fx_vbpre_kernel: the passes are dependent byte
 // swaps, slow through global memory), else in place
-#define DEC_LDS 12288
+#define DEC_LDS 4608
 __device__ __forceinline__ void deinterleave_staged(uint8_t *buf, uint32_t n, uint8_t *X, int lane)
 {
     if (!X || n + 16u > DEC_LDS) { deinterleave_wave(buf, n, lane); return; }
