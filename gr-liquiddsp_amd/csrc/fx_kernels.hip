@@ -2560,7 +2560,7 @@ extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wav
 // but the previous step.
 //
 // Enough lanes come from cutting every frame's trellis into blocks of `blk` steps that run in parallel.  A block other than
-// the first does not know its start metrics; it runs FX_VB_WARM steps of warm-up from all-equal metrics first.  Survivor
+// the first does not know its start metrics; it runs vb_warm(p) (64 to 128) steps of warm-up from all-equal metrics first.  Survivor
 // paths merge within a few constraint lengths, after which the metric DIFFERENCES -- all that add-compare-select decisions
 // depend on -- are the true ones.  That is not assumed but verified: every block records its metric differences at the start
 // of its region and at its end; fx_vbpost_kernel checks block b's start against block b-1's end and, on a mismatch, runs
@@ -2703,6 +2703,9 @@ __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t
 #define VB_ST_BAD 0x10000u        // the block's start differences are not the end differences of the block before it
 #define VB_ST_REP 0x20000u        // ... were not: the block has been run again from the true ones
 static_assert(FX_VB_WARM <= 128, "trellis blocks are at least 128 steps: a block's warm-up must fit into the block before it");
+// warm-up steps by puncturing period: the rate-1/2 code merges fastest; the high-rate punctured codes (5/6, 6/7, 7/8) carry
+// little redundancy per step and take longest (at marginal SNR a 96-step warm-up left every sixth of their blocks to be run again)
+__device__ __forceinline__ uint32_t vb_warm(int p) { return p == 1 ? 64u : (p >= 5 ? 128u : (uint32_t)FX_VB_WARM); }
 #ifndef FX_VB_TWARM
 #define FX_VB_TWARM 128           // traceback warm-up: steps of the next block traced from state 0 to guess the block's end state
 #endif
@@ -2794,7 +2797,7 @@ struct VbHalf {                       // one of a lane's two work items
     const uint8_t *enc; uint32_t t_reg, t1; bool on, first; unsigned long long *dwl; uint8_t *vec;
 };
 
-// Forward pass of a lane's two trellis blocks (same puncturing code p): FX_VB_WARM steps of warm-up from all-equal
+// Forward pass of a lane's two trellis blocks (same puncturing code p): vb_warm(p) steps of warm-up from all-equal
 // metrics (a frame's first block idles instead and starts from the encoder's state), then blk region steps whose decisions
 // go to the blocks' slabs; start and end metric differences to the blocks' vector slots.
 __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A, const VbHalf &B)
@@ -2804,16 +2807,17 @@ __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A
     for (int i = 0; i < 64; i++) Q[i] = 0u;
     unsigned pa, pb; vb_punct(p, pa, pb);
     const unsigned up = (unsigned)p;
+    const uint32_t warm = vb_warm(p);
     VbStream sa, sb;
     {
-        const uint32_t tsa = A.first ? A.t_reg : A.t_reg - FX_VB_WARM, tsb = B.first ? B.t_reg : B.t_reg - FX_VB_WARM;
+        const uint32_t tsa = A.first ? A.t_reg : A.t_reg - warm, tsb = B.first ? B.t_reg : B.t_reg - warm;
         sa.col = tsa % up; sa.nb = (p == 1) ? 2u * tsa : tsa + (tsa + up - 1u) / up; sa.w0 = sa.w1 = sa.wbase = 0;
         sb.col = tsb % up; sb.nb = (p == 1) ? 2u * tsb : tsb + (tsb + up - 1u) / up; sb.w0 = sb.w1 = sb.wbase = 0;
     }
     const uint32_t *ea = reinterpret_cast<const uint32_t *>(A.enc), *eb = reinterpret_cast<const uint32_t *>(B.enc);   // (byte_off is a multiple of 16)
-    const uint32_t nsteps = FX_VB_WARM + blk;
+    const uint32_t nsteps = warm + blk;
     for (uint32_t u = 0; u < nsteps; u += 2) {
-        if (u == FX_VB_WARM) {
+        if (u == warm) {
             // the encoder's start state for a first block (every other state out of reach: beaten by anything real within
             // six steps); the record of the start differences for the others
             if (A.first) {
@@ -2831,13 +2835,13 @@ __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A
             sa.w0 = __builtin_bswap32(x0); sa.w1 = __builtin_bswap32(x1); sa.wbase = ia << 5;
             sb.w0 = __builtin_bswap32(y0); sb.w1 = __builtin_bswap32(y1); sb.wbase = ib << 5;
         }
-        const bool in_reg = u >= FX_VB_WARM;
+        const bool in_reg = u >= warm;
         const bool run_a = in_reg || !A.first, run_b = in_reg || !B.first;     // (a block that idles keeps its stream position)
         unsigned long long a0, b0, a1, b1;
         vb2_step(Q, N, pa, pb, up, sa, sb, run_a, run_b, a0, b0);
         vb2_step(N, Q, pa, pb, up, sa, sb, run_a, run_b, a1, b1);
         // (regions are an even number of steps long within the slab: step ur + 1 is inside it whenever ur is)
-        const uint32_t ur = u - FX_VB_WARM;
+        const uint32_t ur = u - warm;
         if (A.on && in_reg && A.t_reg + ur < A.t1) { A.dwl[(size_t)ur * 64u] = a0; A.dwl[(size_t)(ur + 1u) * 64u] = a1; }
         if (B.on && in_reg && B.t_reg + ur < B.t1) { B.dwl[(size_t)ur * 64u] = b0; B.dwl[(size_t)(ur + 1u) * 64u] = b1; }
     }
@@ -2909,7 +2913,7 @@ void fx_vbfwd1_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t i
     const bool first = !it.on || it.b == 0;
     if (it.on) vb_st[slot] = 0u;
     vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, first ? 1 : 0, nullptr, vb_slab(dwv, slot, blk), first ? nullptr : vec, vec + 64,
-               FX_VB_WARM + blk, FX_VB_WARM, it.on);
+               vb_warm(p) + blk, vb_warm(p), it.on);
 }
 
 __device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
