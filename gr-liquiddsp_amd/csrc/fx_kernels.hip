@@ -2,19 +2,26 @@
 //
 // What liquid-dsp does one sample at a time inside flexframesync_execute / qdetector_cccf_execute
 // (call sites /root/reference/lib/flex_rx_impl.cc:213 and /root/reference/lib/frame_detector_cc_impl.cc:77)
-// is regrouped here into four kernels:
+// is regrouped here into the kernels of one stream-ordered chain per block of input (fx_host.cpp enqueues it):
 //
 //   fx_walk_kernel      one workgroup walks one stream segment through the synchroniser's state
 //                       machine: hop-wise FFT cross-correlation with the +-24-bin CFO sweep
 //                       (qdetector SEEK), ALIGN estimates (tau, gamma, dphi, phi), then -- flex_rx mode --
 //                       NCO mix + polyphase MF of the preamble/header span, pilot sync, header decode.
-//                       Emits one FxFrame per detection and the position where the detector restarts.
+//                       Emits one FxFrame per detection, the hand-off to the next segment, and the runs of hops it skipped.
+//   fx_seekverify_kernel  the exact detector on every skipped hop (thousands of independent workgroups).
+//   fx_chainfast_kernel   stitches the segments' lists into the sequential machine's list; resume state, carried tail
+//                       (fx_chain_kernel: the full-size fallback that can walk by itself).
+//   fx_plan_kernel, fx_planlists_kernel   arena offsets, jobs, result records, work lists of the payload stage.
 //   fx_paymf_kernel     per frame, data parallel: closed-form NCO mix (32-bit phase) + fixed-branch
 //                       polyphase matched filter + decimate-by-2 over the payload span.
 //   fx_paypll_kernel    one lane per frame: the decision-directed payload PLL (the only true
 //                       sample-to-sample recurrence of the path), hard demod, EVM.
-//   fx_paydec_kernel    one wavefront per frame: bit de-interleave, K=7 Viterbi (lane = state),
-//                       block codes, de-whitening, CRC.
+//   fx_vbpre / fx_vbfwd / fx_vbfix / fx_vbtrace / fx_vbfinish   packet decode with the K=7 Viterbi run a lane per trellis
+//                       block (two blocks per lane, packed 16-bit metrics), hand-overs speculated and verified.
+//   fx_paydec_kernel    one wavefront per frame (lane = trellis state): soft decisions, Reed-Solomon, frames without a
+//                       convolutional inner code, and whatever the batch path hands back.
+//   fx_softdemod_kernel, fx_symcopy_kernel, fx_txgen_kernel, fx_txenc_kernel   optional stage / results / frame generator.
 //
 // No MFMA anywhere: nothing on this path is a dense contraction.  Taps, windows, spectra and the
 // FFT exchange buffers live in LDS; IQ is read from HBM as coalesced float2.
