@@ -5,12 +5,18 @@
 // the host never waits between them:
 //
 //   walkers (speculative segments)      -- fx_walk_kernel, launched at once
-//   [wait: chain kernel of the previous block]   -- an event, on the device
+//   seek verification, phase 0          -- fx_seekverify_kernel over the runs those walkers emitted (continuing streams only)
+//   [wait: chain kernel of the previous block]   -- an event, on the device; from here to the chain kernel a block of
+//                                          continuing streams is on the context's high-priority stream
 //   true walkers of continuing streams  -- fx_walk_kernel; their start state is read from device memory
-//   seek verification                   -- fx_seekverify_kernel over the runs the walkers emitted
-//   chain                               -- fx_chain_kernel: stitch / repair / resume state / carried tail, per stream
-//   plan                                -- fx_plan_kernel: payload jobs, work lists, host result records
+//   seek verification (phase 1)         -- the remaining runs
+//   chain                               -- fx_chainfast_kernel: stitch / resume state / carried tail, per stream
+//   plan                                -- fx_plan_kernel + fx_planlists_kernel: payload jobs, work lists, host result records
 //   payload MF -> PLL -> packet decode  -- results land in pinned host memory
+//
+// Slow paths, all at fxrx_collect (repair_and_replay, finish_decode): repair rounds (segments walked again in parallel:
+// hand-off misses, fired skipped hops), the full-size fx_chain_kernel, a whole-block walk without hop skipping, carry
+// buffers that have to grow, decode launches that the hint-sized grids did not cover.
 //
 // Why segments: liquid's synchroniser is one sequential state machine per stream (where the detector restarts after a
 // frame depends on that frame's header).  Each stream is cut into segments that are walked concurrently from a
