@@ -164,7 +164,7 @@ struct Slot {
     DevBuf<unsigned long long> d_vb_dw;      // its decision words, step-major within the 64 work items of a wave
     DevBuf<uint32_t> d_vb_st;                // traceback states and flags per work item
     uint32_t vb_cap = 0, vb_blk = 0, vb_pre_launched = 0, vb_items_launched = 0, fb_launched = 0;
-    uint64_t vb_dw_words = 0;
+    uint64_t vb_dw_words = 0, vb_slots_alloc = 128;
     DevBuf<FxPayJob> d_pjobs; DevBuf<FxPayResult> d_pres;
     uint32_t run_cap = 0, chain_cap = 0, mf_cap = 0, frame_slots = 0;
     uint64_t sym_cap = 0, byte_cap = 0, dw_cap = 0, out_cap = 0;
@@ -496,6 +496,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         // (the decision-word arena itself: the same number of words whatever the block length -- the 2048 extra work items
         // priced at the longest block --, or a change of block length by one notch would reallocate it, 1.5 x larger)
         sl.vb_dw_words = sl.vb_blk ? std::max<uint64_t>((uint64_t)sl.vb_cap * sl.vb_blk, steps_cap + 2176ull * 4096ull) : 0;
+        sl.vb_slots_alloc = sl.vb_blk ? std::max<uint64_t>(sl.vb_cap, steps_cap / 192 + 2176) : 128;     // likewise the per-item arenas: priced at the shortest block
     }
     if (sl.sym_cap >= (1ull << 32) || sl.dw_cap >= (1ull << 32)) { set_err("fxrx_submit: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
 
@@ -515,8 +516,8 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         if (sl.d_plan_ws.reserve(fx_plan_ws_words())) return FXRX_ERR_HIP;
         HIP_OK(hipMemsetAsync(sl.d_plan_ws.p, 0, fx_plan_ws_words() * sizeof(uint32_t), st));
     }
-    if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_cap) ||
-        (sl.vb_blk && (sl.d_vb_vec.reserve(128 * (size_t)sl.vb_cap) || sl.d_vb_dw.reserve((size_t)sl.vb_dw_words) || sl.d_vb_st.reserve(sl.vb_cap)))) return FXRX_ERR_HIP;
+    if (sl.d_vb_items.reserve(2 * (size_t)sl.vb_slots_alloc) ||
+        (sl.vb_blk && (sl.d_vb_vec.reserve(128 * (size_t)sl.vb_slots_alloc) || sl.d_vb_dw.reserve((size_t)sl.vb_dw_words) || sl.d_vb_st.reserve(sl.vb_slots_alloc)))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.soft_decision && (sl.d_soft.reserve(8 * sl.byte_cap) || (c->cfg.want_framesyms && sl.h_soft.reserve(8 * sl.byte_cap)))) return FXRX_ERR_HIP;
 #ifdef FX_STAMPS
     if (!detect && sl.d_pres.reserve(chain_slots)) return FXRX_ERR_HIP;
