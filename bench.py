@@ -95,11 +95,12 @@ def free_port():
     return p
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, script=None):
     """--gpus N without a launcher: start N fresh child processes (one per GPU) and wait for them.  The parent never
-    imports torch and never touches the GPU.  Returns the worst child exit code."""
+    imports torch and never touches the GPU.  Returns the worst child exit code.  (script: tools/bench_configs.py starts its
+    ranks through here as well.)"""
     port = free_port()
-    procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=rank_env(r, n, port)) for r in range(n)]
+    procs = [subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + list(argv), env=rank_env(r, n, port)) for r in range(n)]
     rc = 0
     try:
         pending = list(procs)
@@ -196,6 +197,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-pipeline", action="store_true", help="one block in flight (latency mode)")
     ap.add_argument("--depth", type=int, default=12, help="blocks in flight in the timed region")
     ap.add_argument("--segment", type=int, default=0, help="speculation segment length in samples (0 = library default)")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE config: 2 = the headline line (default); 3 / 4 / 5 = tools/bench_configs.py (distinct streams generated on the device; "
+                         "config 5: 1024 streams sharded over --gpus ranks)")
     ap.add_argument("--continuous", action="store_true",
                     help="feed the passes as consecutive blocks of ONE continuing stream (no reset in between): not the headline number")
     return ap.parse_args(argv)
@@ -217,6 +221,10 @@ def main(argv=None):
     a = parse_args(argv)
     argv = list(sys.argv[1:] if argv is None else argv)
     stub = os.environ.get("BENCH_STUB", "0") == "1"
+    if a.config != 2:                                      # the other BASELINE configs have their own runner (same launcher, same rendezvous)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_configs
+        return bench_configs.main(["--only", str(a.config), "--gpus", str(a.gpus), "--passes", str(max(1, min(a.steps, 5)))] + (["--no-pipeline"] if a.no_pipeline else []))
     if "RANK" not in os.environ and a.gpus > 1:
         raise SystemExit(launch_ranks(a.gpus, argv))
 
@@ -373,6 +381,7 @@ def main(argv=None):
     if not a.no_constellation and not stub and not a.continuous:
         ctx.reset()
         dtc, repsc, nresc = timed(make_runner(ctx, None, cont=True), max(1, a.steps // 4), a.min_time / 2)
+        check(ctx, nresc)                                    # (the capture ends in noise: every block of the continuing stream holds the same whole frames)
         pc = max(1, a.steps // 4) * repsc
         as_stream = dict(value=round(world * a.samples / (dtc / pc) / 1e6, 2), ms_per_step=round(dtc / pc * 1e3, 4), passes_timed=pc)
         ctx.reset()
@@ -391,6 +400,48 @@ def main(argv=None):
         with_h2d = dict(value=round(world * a.samples / (dt3 / p3) / 1e6, 2), ms_per_step=round(dt3 / p3 * 1e3, 4), passes_timed=p3, h2d_bytes_per_step=int(8 * a.samples))
         ctx3.close()
 
+    # fourth figure: what the reference's block really moves -- IQ from host memory in, the constellation of every frame out
+    # (lib/flex_rx_impl.cc:208,217-221) -- both PCIe directions inside every step
+    with_io = None
+    if not a.no_constellation and not stub:
+        ctx4 = fx.RxContext(1, device=local, segment_len=a.segment, want_framesyms=True)
+        ctx4.reset(); check(ctx4, ctx4.process_raw([xh.data_ptr()], counts, False))
+        ctx4.set_depth(depth)
+        dt4, reps4, nres4 = timed(make_runner(ctx4, None, [xh.data_ptr()], False), max(1, a.steps // 4), a.min_time / 2)
+        check(ctx4, nres4)
+        p4 = max(1, a.steps // 4) * reps4
+        with_io = dict(value=round(world * a.samples / (dt4 / p4) / 1e6, 2), ms_per_step=round(dt4 / p4 * 1e3, 4), passes_timed=p4,
+                       h2d_bytes_per_step=int(8 * a.samples), d2h_bytes_per_step=int(8 * tm["payload_symbols"]))
+        ctx4.close()
+
+    # fifth figure: through the boundary the reference has -- the C++ flex_rx block shell fed by work() calls of 4096 items from
+    # pageable memory, flexframesync_execute(q, in, 256) inside (lib/flex_rx_impl.cc:212-215), three messages per frame built
+    # and checked (csrc/blocks/dropin_feed.cpp)
+    dropin = None
+    if not a.no_constellation and not stub and world == 1:
+        import ctypes as C
+        F = fx._ffi.feed_lib()
+        st = fx._ffi.DropinStats()
+        want_hash = fx._ffi.fnv1a([pl for _, pl in injected])
+
+        def feed(reps):
+            if F.dropin_feed(x.ctypes.data, len(x) - len(x) % 256, 4096, reps, C.byref(st)) != 0:
+                raise SystemExit("bench: drop-in block could not be created: " + fx.lib().fxrx_last_error().decode())
+            return st.seconds
+        t1 = feed(1)
+        if (st.frames, st.header_valid, st.payload_valid, st.errors) != (len(injected), len(injected), len(injected), 0) or st.payload_hash != want_hash:
+            raise SystemExit("bench: drop-in path published %d frames (%d valid) of %d -- refusing to report a throughput" % (st.frames, st.payload_valid, len(injected)))
+        rd = max(2, int(math.ceil(a.min_time / max(t1, 1e-3))))
+        td = feed(rd)
+        if st.frames != rd * len(injected) or st.payload_valid != rd * len(injected) or st.errors:
+            raise SystemExit("bench: drop-in path lost frames in the timed run")
+        dropin = dict(value=round(rd * (len(x) - len(x) % 256) / td / 1e6, 2), unit="Msamples/s", passes_timed=rd, seconds=round(td, 3), items_per_work=4096, samples_per_execute=256,
+                      block_samples=int(os.environ.get("FXRX_SYNC_BLOCK", 1 << 20)), blocks_in_flight=int(os.environ.get("FXRX_SYNC_DEPTH", 3)),
+                      first_frame_latency_ms=round(st.first_frame_seconds * 1e3, 2),
+                      host_to_device_gbs=round(8.0 * rd * len(x) / td / 1e9, 2), constellation_to_host_gbs=round(8.0 * st.constellation_syms / td / 1e9, 2),
+                      note="pageable host IQ -> memcpy into pinned ring -> async upload + kernel chain per 2^20-sample block of one continuing stream; "
+                           "frames, payloads and constellations delivered through the callback, one per call")
+
     if rank == 0:
         # HIP events bracket the stages of a block's kernel chain.  Four stages are a single kernel; the stitch stage is two small
         # ones and the decode stage six (batch Viterbi: front part, forward pass, hand-over check x2, traceback, back part, plus
@@ -399,7 +450,7 @@ def main(argv=None):
         # stage of a block on its own.  (Fixed, not picked per run: walker and PLL are close under load and would swap places.)
         names = dict(walk_ms="fx_walk_kernel", seekverify_ms="fx_seekverify_kernel", chain_ms="fx_chainfast_kernel+fx_plan_kernel", paymf_ms="fx_paymf_kernel",
                      paypll_ms="fx_paypll_kernel", paydec_ms="decode stage (fx_vbpre/vbfwd/vbfix/vbtrace/vbfinish_kernel + fx_paydec_kernel)")
-        dom = "paypll_ms"      # (23 % of all kernel time in profiles/r02_bench_kernel_stats.csv; the walker follows with 22 %)
+        dom = "paypll_ms"      # (the largest share of all kernel time in the rocprofv3 summary of this command, profiles/README.md; the walker follows)
         alg_bytes = BYTES_PER_SAMPLE * a.samples
         achieved = alg_bytes / (live[dom] * 1e-3) / 1e9
         out = {
@@ -434,6 +485,12 @@ def main(argv=None):
         if as_stream is not None:
             out["value_one_continuing_stream"] = as_stream["value"]
             out["one_continuing_stream"] = as_stream
+        if with_io is not None:
+            out["value_with_h2d_and_constellation_d2h"] = with_io["value"]
+            out["with_h2d_and_constellation_d2h"] = with_io
+        if dropin is not None:
+            out["value_through_dropin_abi"] = dropin["value"]
+            out["through_dropin_abi"] = dropin
         out["whole_path_hbm_gbs_iq_only"] = round(8.0 * a.samples / (dt / passes) / 1e9, 2)        # the "IQ-only" figure (8 B/sample)
         if world == 1 and not a.no_cpu_baseline:
             one, allc = cpu_baseline(x)

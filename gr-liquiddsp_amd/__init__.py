@@ -12,8 +12,8 @@ Layers (bottom up):
 from . import _ffi
 from ._ffi import build, lib, LIB_PATH
 from .rx import RxContext, MODE_FLEX_RX, MODE_DETECTOR
-from .tx import FrameGen, TxContext, synth_stream, MOD_BY_INDEX, INNER_BY_INDEX, OUTER_BY_INDEX, CRC_24, CRC_32
+from .tx import FrameGen, TxContext, synth_stream, synth_streams_device, MOD_BY_INDEX, INNER_BY_INDEX, OUTER_BY_INDEX, CRC_24, CRC_32
 from .blocks import flex_rx, frame_detector_cc, flex_tx
 
-__all__ = ["build", "lib", "RxContext", "FrameGen", "TxContext", "synth_stream", "flex_rx", "frame_detector_cc", "flex_tx",
+__all__ = ["build", "lib", "RxContext", "FrameGen", "TxContext", "synth_stream", "synth_streams_device", "flex_rx", "frame_detector_cc", "flex_tx",
            "MODE_FLEX_RX", "MODE_DETECTOR"]

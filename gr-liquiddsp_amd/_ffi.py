@@ -36,6 +36,10 @@ class TxFrame(C.Structure):                 # fxtx_frame
                 ("dt", C.c_float), ("out_offset", C.c_ulonglong)]
 
 
+class TxChannel(C.Structure):               # fxtx_channel
+    _fields_ = [("cfo", C.c_float), ("phase", C.c_float), ("gain", C.c_float), ("sigma", C.c_float), ("seed", C.c_ulonglong)]
+
+
 class Config(C.Structure):                  # fxrx_config
     _fields_ = [("device", C.c_int), ("mode", C.c_int), ("n_streams", C.c_uint), ("threshold", C.c_float),
                 ("segment_len", C.c_uint), ("want_framesyms", C.c_int), ("equalizer", C.c_int), ("soft_decision", C.c_int)]
@@ -80,14 +84,48 @@ EXPORTS = [
     "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
     "fxrx_outer_from_index", "fxrx_outer_to_index",
     "fxtx_create", "fxtx_destroy", "fxtx_frame_len", "fxtx_generate",
+    "fxtx_apply_channel", "fxrx_ready", "fxrx_inflight", "fxrx_debug_fail", "fxrx_pinned_alloc", "fxrx_pinned_free", "fxrx_sync_context",
 ]
+
+
+class DropinStats(C.Structure):            # dropin_stats of csrc/blocks/dropin_feed.cpp
+    _fields_ = [("seconds", C.c_double), ("frames", C.c_uint64), ("header_valid", C.c_uint64), ("payload_valid", C.c_uint64),
+                ("payload_bytes", C.c_uint64), ("constellation_syms", C.c_uint64), ("packet_infos", C.c_uint64),
+                ("payload_hash", C.c_uint64), ("errors", C.c_uint64), ("first_frame_seconds", C.c_double)]
+
+
+_feed = None
+
+
+def feed_lib():
+    """libdropin_feed.so: drives the C++ flex_rx block shell over a host buffer in 256-sample flexframesync_execute calls."""
+    global _feed
+    if _feed is None:
+        lib()
+        L = C.CDLL(os.path.join(CSRC, "libdropin_feed.so"))
+        L.dropin_feed.restype = C.c_int
+        L.dropin_feed.argtypes = [C.c_void_p, C.c_ulonglong, C.c_uint, C.c_uint, C.POINTER(DropinStats)]
+        L.dropin_feed_threads.restype = C.c_int
+        L.dropin_feed_threads.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_ulonglong), C.c_uint, C.c_uint, C.POINTER(DropinStats)]
+        _feed = L
+    return _feed
+
+
+def fnv1a(chunks):
+    """FNV-1a (64 bit) over the concatenation of byte strings: what dropin_feed hashes the payload_data messages with."""
+    import numpy as np
+    h = 14695981039346656037
+    for b in chunks:
+        for v in b:
+            h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
 
 
 def build(force=False):
     """Compile libfxrx.so for gfx950 with hipcc (cross-compiles without a GPU)."""
     if force:
         subprocess.check_call(["make", "-C", CSRC, "clean"], stdout=subprocess.DEVNULL)
-    subprocess.check_call(["make", "-C", CSRC], stdout=subprocess.DEVNULL)
+    subprocess.check_call(["make", "-j4", "-C", CSRC, "all"], stdout=subprocess.DEVNULL)
     return LIB_PATH
 
 
@@ -122,6 +160,12 @@ def lib():
     L.fxrx_submit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
     L.fxrx_collect.restype = C.c_int; L.fxrx_collect.argtypes = [C.c_void_p]
     L.fxrx_set_depth.restype = C.c_int; L.fxrx_set_depth.argtypes = [C.c_void_p, C.c_uint]
+    L.fxrx_ready.restype = C.c_int; L.fxrx_ready.argtypes = [C.c_void_p]
+    L.fxrx_inflight.restype = C.c_uint; L.fxrx_inflight.argtypes = [C.c_void_p]
+    L.fxrx_debug_fail.restype = C.c_int; L.fxrx_debug_fail.argtypes = [C.c_void_p, C.c_uint, C.c_uint]
+    L.fxrx_pinned_alloc.restype = C.c_void_p; L.fxrx_pinned_alloc.argtypes = [C.c_size_t]
+    L.fxrx_pinned_free.restype = None; L.fxrx_pinned_free.argtypes = [C.c_void_p]
+    L.fxrx_sync_context.restype = C.c_void_p; L.fxrx_sync_context.argtypes = [C.c_void_p]
     L.fxrx_debug_stamps.restype = C.c_int; L.fxrx_debug_stamps.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_uint32 * 8)]
     L.fxrx_debug_chain_stamps.restype = C.c_int; L.fxrx_debug_chain_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8)]
     L.fxrx_debug_walk_stamps.restype = C.c_int; L.fxrx_debug_walk_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
@@ -135,6 +179,8 @@ def lib():
     L.fxtx_frame_len.restype = C.c_uint; L.fxtx_frame_len.argtypes = [C.POINTER(TxFrame)]
     L.fxtx_generate.restype = C.c_int
     L.fxtx_generate.argtypes = [C.c_void_p, C.POINTER(TxFrame), C.c_uint, C.c_void_p, C.c_ulonglong]
+    L.fxtx_apply_channel.restype = C.c_int
+    L.fxtx_apply_channel.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_ulonglong, C.POINTER(TxChannel)]
     for n in ("mod", "inner", "outer"):
         f = getattr(L, "fxrx_%s_from_index" % n); f.restype = C.c_int; f.argtypes = [C.c_int]
         f = getattr(L, "fxrx_%s_to_index" % n); f.restype = C.c_int; f.argtypes = [C.c_uint]

@@ -62,20 +62,29 @@ public:
     static sptr make() { return sptr(new flex_rx()); }                       // include/liquiddsp/flex_rx.h:50
     ~flex_rx() { flexframesync_destroy(d_fs); }                              // lib/flex_rx_impl.cc:71
 
-    // lib/flex_rx_impl.cc:203-254
+    // lib/flex_rx_impl.cc:203-254: the reference's loop as it stands -- 256 samples per call, at most one frame drained after each
     int work(int noutput_items, gr_vector_const_void_star &input_items, gr_vector_void_star &)
     {
-        fx_complex *in = (fx_complex *)input_items[0];
+        fx_complex *in = (fx_complex *)input_items[0];                       // :208
         if (noutput_items % d_inbuf_len != 0) throw std::invalid_argument("flex_rx: noutput_items must be a multiple of 256");   // :210
-        fxrx_sync_set_block(d_fs, (unsigned)noutput_items);
-        flexframesync_execute(d_fs, in, (unsigned)noutput_items);           // :213, whole block in one call
-        for (;;) {
-            if (d_info._new_payload) { publish(); d_info._new_payload = false; }                                  // :216-250
-            if (!fxrx_sync_pending(d_fs)) break;
-            flexframesync_execute(d_fs, in, 0);
+        int num_items = 0;
+        while (num_items < noutput_items) {                                  // :212
+            flexframesync_execute(d_fs, in, d_inbuf_len);                    // :213
+            num_items += d_inbuf_len; in += d_inbuf_len;                     // :214-215
+            if (d_info._new_payload) { publish(); d_info._new_payload = false; }   // :216-250
         }
         return noutput_items;                                                // :253
     }
+    // (additive; a GNU Radio shell would call it from stop()): run what is still queued, publish every frame that completes
+    void flush()
+    {
+        fxrx_sync_flush(d_fs);
+        while (fxrx_sync_pending(d_fs)) {
+            flexframesync_execute(d_fs, nullptr, 0);
+            if (d_info._new_payload) { publish(); d_info._new_payload = false; }
+        }
+    }
+    flexframesync handle() const { return d_fs; }
     unsigned long num_frames() const { return d_info._num_frames; }
 
 private:

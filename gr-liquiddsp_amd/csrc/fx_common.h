@@ -248,6 +248,13 @@ struct FxTxTables {
     float2   pn[FX_PN_LEN], pilots[16];
 };
 
+// ---- synthetic channel of the generator (fx_channel_kernel): per stream, y[n] = gain x[n] exp(j (th0 + n dl)) + sigma w[n] ----
+struct FxChannel {
+    uint32_t th0, dl;       // carrier phase / phase increment per sample, 2^32 = one turn
+    float    gain, sigma;   // sigma: standard deviation of the noise per real dimension
+    uint64_t seed;          // key of the counter-based noise generator (Philox-4x32-10, counter = sample index / 2)
+};
+
 // ---- payload stage records (built on the device by fx_plan_kernel) ----
 struct FxPayJob {           // one per chain frame; nsym == 0: no payload stage (header invalid / detector mode)
     const float2 *x, *xa_end;   // stream samples (two pieces, see FxWalkJob)

@@ -1,5 +1,6 @@
 // fx_dropin.cpp -- the liquid-dsp entry points that gr::liquiddsp's blocks call, re-hosted on the
 // batched GPU context (include/fxrx.h, layer 1).  Each function cites the reference call site it serves.
+#include <algorithm>
 #include <deque>
 #include <memory>
 #include <vector>
@@ -12,95 +13,177 @@
 
 namespace {
 
+// A completed frame waiting for its callback.  Buffers are BORROWED from the context's result arenas (pinned host memory the
+// kernels wrote into; valid until the next fxrx_collect on the context) unless `own` holds copies.
 struct HeldFrame {
     unsigned char header[20]; int header_valid = 0, payload_valid = 0;
-    std::vector<unsigned char> payload; std::vector<fx_complex> syms;
+    const unsigned char *payload = nullptr; unsigned payload_len = 0;
+    const fx_complex *syms = nullptr; unsigned nsyms = 0;
+    bool owned = false; std::vector<unsigned char> own_payload; std::vector<fx_complex> own_syms;
     framesyncstats_s stats{};
+    void materialise()                      // take copies: the arenas are about to be reused
+    {
+        if (owned) return;
+        if (payload && payload_len) { own_payload.assign(payload, payload + payload_len); payload = own_payload.data(); }
+        if (syms && nsyms) { own_syms.assign(syms, syms + nsyms); syms = own_syms.data(); }
+        owned = true;
+    }
 };
+
+constexpr unsigned kSyncBlockDefault = 1u << 20;    // samples per GPU block (fxrx_sync_set_block / FXRX_SYNC_BLOCK); see DESIGN.md section 7
+constexpr unsigned kSyncDepthDefault = 3;           // blocks in flight (FXRX_SYNC_DEPTH)
+constexpr unsigned kSyncPollEvery = 4096;           // samples between two looks at whether the oldest block has finished
 
 }  // namespace
 
 // ------------------------------------------------------------------------------------------ flexframesync
+// The reference feeds 256 samples per call from pageable memory (/root/reference/lib/flex_rx_impl.cc:212-215).  Here a call
+// copies them into the pinned buffer being filled; a full buffer is submitted as one block of the continuing stream
+// (fxrx_submit: upload and the whole kernel chain are enqueued, nothing is waited for) and the next buffer of the ring is
+// filled while up to `depth` blocks are in flight.  Finished blocks are collected when a slot is needed or when a poll
+// (every few thousand samples) finds the oldest one done; their frames wait in `pending` and leave one per call.
 struct fxrx_sync_s {
     framesync_callback cb = nullptr; void *ud = nullptr;
     fxrx_ctx *ctx = nullptr; float threshold = 0.0f; int equalizer = 0, soft = 0;
-    std::vector<fx_complex> queue; unsigned block = 1u << 16;
+    unsigned block = kSyncBlockDefault, depth = kSyncDepthDefault;
+    std::vector<fx_complex *> bufs; unsigned cur = 0; size_t fill = 0;     // ring of depth + 1 pinned input buffers of `block` samples
     std::deque<HeldFrame> pending; HeldFrame current;
+    unsigned errors = 0, since_poll = 0;
 
-    unsigned errors = 0;
-    // returns false when the GPU call failed: the samples stay queued (they run again with the next call), the error
-    // text stays in fxrx_last_error(), one line goes to stderr, `errors` counts
-    bool run()
+    ~fxrx_sync_s() { free_bufs(); }
+    void free_bufs() { for (auto p : bufs) fxrx_pinned_free(p); bufs.clear(); cur = 0; fill = 0; }
+    bool alloc_bufs()
     {
-        const void *p = queue.data(); uint64_t n = queue.size();
-        int nr = ctx ? fxrx_process(ctx, &p, &n, 0) : FXRX_ERR_STATE;
-        if (nr < 0) {
-            if (errors++ == 0 || (errors & (errors - 1)) == 0)
-                std::fprintf(stderr, "libfxrx: flexframesync_execute: block of %llu samples failed (%d): %s [%u failures so far]\n",
-                             (unsigned long long)n, nr, ctx ? fxrx_last_error() : "no context", errors);
-            if (queue.size() > (size_t)64 * block) queue.erase(queue.begin(), queue.end() - (std::ptrdiff_t)(32 * (size_t)block));   // bounded
-            return false;
-        }
-        queue.clear();
-        for (int i = 0; i < nr; i++) {
-            fxrx_frame f; if (fxrx_result(ctx, (unsigned)i, &f) != 0) continue;
-            HeldFrame h;
-            std::memcpy(h.header, f.header, 20); h.header_valid = f.header_valid; h.payload_valid = f.payload_valid;
-            if (f.payload && f.payload_len) h.payload.assign(f.payload, f.payload + f.payload_len);
-            if (f.framesyms && f.num_framesyms) h.syms.assign(f.framesyms, f.framesyms + f.num_framesyms);
-            h.stats.evm = f.header_valid ? f.evm_db : 0.0f; h.stats.rssi = f.rssi_db; h.stats.cfo = f.cfo;
-            h.stats.mod_scheme = f.mod_scheme; h.stats.mod_bps = f.mod_bps; h.stats.check = f.check; h.stats.fec0 = f.fec0; h.stats.fec1 = f.fec1;
-            pending.push_back(std::move(h));
+        free_bufs();
+        for (unsigned i = 0; i < depth + 1; i++) {
+            fx_complex *p = (fx_complex *)fxrx_pinned_alloc((size_t)block * sizeof(fx_complex));
+            if (!p) { free_bufs(); return false; }
+            bufs.push_back(p);
         }
         return true;
     }
+    void report(const char *what, int rc)
+    {
+        if (errors++ == 0 || (errors & (errors - 1)) == 0)
+            std::fprintf(stderr, "libfxrx: %s failed (%d): %s [%u failures so far]\n", what, rc, ctx ? fxrx_last_error() : "no context", errors);
+    }
+    // the oldest block in flight: wait for it, queue its frames
+    void collect_one()
+    {
+        for (auto &h : pending) h.materialise();           // (rare: frames are normally delivered long before the next block is due)
+        current.materialise();
+        const int nr = fxrx_collect(ctx);
+        if (nr < 0) { report("flexframesync_execute: block", nr); return; }     // (every block in flight was dropped with it; the streams restart fresh)
+        for (int i = 0; i < nr; i++) {
+            fxrx_frame f; if (fxrx_result(ctx, (unsigned)i, &f) != 0) continue;
+            pending.emplace_back();
+            HeldFrame &h = pending.back();
+            std::memcpy(h.header, f.header, 20); h.header_valid = f.header_valid; h.payload_valid = f.payload_valid;
+            h.payload = f.payload_len ? f.payload : nullptr; h.payload_len = f.payload ? f.payload_len : 0;
+            h.syms = f.num_framesyms ? f.framesyms : nullptr; h.nsyms = f.framesyms ? f.num_framesyms : 0;
+            h.stats.evm = f.header_valid ? f.evm_db : 0.0f; h.stats.rssi = f.rssi_db; h.stats.cfo = f.cfo;
+            h.stats.mod_scheme = f.mod_scheme; h.stats.mod_bps = f.mod_bps; h.stats.check = f.check; h.stats.fec0 = f.fec0; h.stats.fec1 = f.fec1;
+        }
+    }
+    // hand the buffer being filled to the GPU as the stream's next block
+    void submit_current()
+    {
+        if (!fill) return;
+        if (fxrx_inflight(ctx) >= depth) collect_one();
+        const void *p = bufs[cur]; uint64_t n = fill;
+        const int r = fxrx_submit(ctx, &p, &n, 0);
+        if (r < 0) {
+            // the context is as it was before the call; these samples are lost to it: restart the synchroniser behind the gap
+            report("flexframesync_execute: submit", r);
+            while (fxrx_inflight(ctx)) collect_one();
+            fxrx_reset(ctx);
+        }
+        cur = (cur + 1) % (unsigned)bufs.size(); fill = 0;
+    }
+    void drain() { while (fxrx_inflight(ctx)) collect_one(); }
     void deliver_one()
     {
         if (pending.empty()) return;
         current = std::move(pending.front()); pending.pop_front();
-        current.stats.framesyms = current.syms.empty() ? nullptr : current.syms.data();
-        current.stats.num_framesyms = (unsigned)current.syms.size();
+        if (current.owned) { current.payload = current.own_payload.empty() ? nullptr : current.own_payload.data(); current.syms = current.own_syms.empty() ? nullptr : current.own_syms.data(); }
+        current.stats.framesyms = const_cast<fx_complex *>(current.syms);
+        current.stats.num_framesyms = current.nsyms;
         if (cb)
-            cb(current.header, current.header_valid, current.payload.empty() ? nullptr : current.payload.data(),
-               (unsigned)current.payload.size(), current.payload_valid, current.stats, ud);
+            cb(current.header, current.header_valid, const_cast<unsigned char *>(current.payload), current.payload_len, current.payload_valid, current.stats, ud);
     }
 };
+
+static fxrx_ctx *sync_make_ctx(const fxrx_sync_s *q)
+{
+    fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1;
+    if (q) { cfg.threshold = q->threshold; cfg.equalizer = q->equalizer; cfg.soft_decision = q->soft; }
+    if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
+    fxrx_ctx *ctx = fxrx_create(&cfg);
+    if (ctx && fxrx_set_depth(ctx, q ? q->depth : kSyncDepthDefault) != 0) { fxrx_destroy(ctx); return nullptr; }
+    return ctx;
+}
 
 extern "C" {
 
 // /root/reference/lib/flex_rx_impl.cc:49
 flexframesync flexframesync_create(framesync_callback callback, void *userdata)
 {
-    fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1;
-    if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
-    fxrx_ctx *ctx = fxrx_create(&cfg);
-    if (!ctx) return nullptr;
-    fxrx_sync_s *q = new fxrx_sync_s; q->cb = callback; q->ud = userdata; q->ctx = ctx;
-    return q;
+    std::unique_ptr<fxrx_sync_s> q(new fxrx_sync_s); q->cb = callback; q->ud = userdata;
+    if (const char *e = std::getenv("FXRX_SYNC_BLOCK")) q->block = (unsigned)std::max(256, std::atoi(e));
+    if (const char *e = std::getenv("FXRX_SYNC_DEPTH")) q->depth = (unsigned)std::min(15, std::max(1, std::atoi(e)));
+    q->ctx = sync_make_ctx(q.get());
+    if (!q->ctx) return nullptr;
+    if (!q->alloc_bufs()) { fxrx_destroy(q->ctx); return nullptr; }
+    return q.release();
 }
 // /root/reference/lib/flex_rx_impl.cc:71
 void flexframesync_destroy(flexframesync q) { if (!q) return; fxrx_destroy(q->ctx); delete q; }
-void flexframesync_reset(flexframesync q) { if (!q) return; fxrx_reset(q->ctx); q->queue.clear(); q->pending.clear(); }
+void flexframesync_reset(flexframesync q)
+{
+    if (!q) return;
+    q->drain(); q->pending.clear(); q->fill = 0;
+    fxrx_reset(q->ctx);
+}
 // /root/reference/lib/flex_rx_impl.cc:213
 void flexframesync_execute(flexframesync q, fx_complex *x, unsigned int n)
 {
     if (!q) return;
-    if (n) q->queue.insert(q->queue.end(), x, x + n);
-    if (q->queue.size() >= q->block) (void)q->run();
+    q->since_poll += n;
+    while (n) {
+        const size_t take = std::min<size_t>(n, (size_t)q->block - q->fill);
+        std::memcpy(q->bufs[q->cur] + q->fill, x, take * sizeof(fx_complex));
+        q->fill += take; x += take; n -= (unsigned)take;
+        if (q->fill == q->block) q->submit_current();
+    }
+    if (q->since_poll >= kSyncPollEvery) {
+        q->since_poll = 0;
+        if (q->pending.empty() && fxrx_ready(q->ctx) == 1) q->collect_one();
+    }
     q->deliver_one();
 }
-void fxrx_sync_flush(flexframesync q) { if (!q) return; if (!q->queue.empty()) (void)q->run(); }
-void fxrx_sync_set_block(flexframesync q, unsigned int samples) { if (q) q->block = samples ? samples : 1; }
+void fxrx_sync_flush(flexframesync q) { if (!q) return; q->submit_current(); q->drain(); }
+void fxrx_sync_set_block(flexframesync q, unsigned int samples)
+{
+    if (!q) return;
+    const unsigned nb = samples < 256 ? 256u : samples;
+    if (nb == q->block) return;
+    fxrx_sync_flush(q);                      // what is queued runs at the old size (buffers move)
+    for (auto &h : q->pending) h.materialise();
+    const unsigned old = q->block;
+    q->block = nb;
+    if (!q->alloc_bufs()) { q->errors++; std::fprintf(stderr, "libfxrx: fxrx_sync_set_block: %s\n", fxrx_last_error()); q->block = old; (void)q->alloc_bufs(); }
+}
 unsigned int fxrx_sync_pending(flexframesync q) { return q ? (unsigned)q->pending.size() : 0; }
 unsigned int fxrx_sync_errors(flexframesync q) { return q ? q->errors : 0; }
+fxrx_ctx *fxrx_sync_context(flexframesync q) { return q ? q->ctx : nullptr; }
 // threshold and equaliser live in the context configuration: make a new context first, swap only if that worked (state is
 // reset, as liquid's setters do not promise otherwise); on failure the old context stays and the error is reported
 static void sync_recreate(flexframesync q, const char *what)
 {
-    fxrx_config cfg{}; cfg.device = 0; cfg.mode = FXRX_MODE_FLEX_RX; cfg.n_streams = 1; cfg.want_framesyms = 1;
-    cfg.threshold = q->threshold; cfg.equalizer = q->equalizer; cfg.soft_decision = q->soft;
-    if (const char *d = std::getenv("FXRX_DEVICE")) cfg.device = std::atoi(d);
-    fxrx_ctx *nc = fxrx_create(&cfg);
+    fxrx_sync_flush(q);
+    for (auto &h : q->pending) h.materialise();
+    q->current.materialise();
+    fxrx_ctx *nc = sync_make_ctx(q);
     if (!nc) { q->errors++; std::fprintf(stderr, "libfxrx: %s: %s (setting unchanged)\n", what, fxrx_last_error()); return; }
     fxrx_destroy(q->ctx);
     q->ctx = nc;

@@ -212,6 +212,8 @@ struct fxrx_ctx_s {
     Slot *last = nullptr;                // slot whose results are currently exposed through fxrx_result
     uint64_t replays = 0, repairs_host = 0, late_decodes = 0;
     unsigned noskip_left = 0;            // blocks still to be walked with the exact detector on every hop (after a verification failure)
+    unsigned debug_fail_submit = 0, debug_fail_collect = 0;   // tests (fxrx_debug_fail): the next n submits / collects report a failure
+    uint64_t discarded = 0;              // blocks dropped by a failing fxrx_collect (see discard_inflight)
 };
 
 namespace {
@@ -288,6 +290,14 @@ const char *fxrx_last_error(void) { return g_err.c_str(); }
 void fxrx_set_error(const char *msg) { set_err(msg ? msg : ""); }      // for the library's other translation units
 const char *fxrx_version(void) { return "fxrx 0.2 (gfx950)"; }
 int fxrx_device_count(void) { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) return 0; return n; }
+// page-locked host memory: uploads from it are asynchronous (fxrx_submit returns while the copy is still under way)
+void *fxrx_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { set_err("fxrx_pinned_alloc: hipHostMalloc failed"); return nullptr; }
+    return p;
+}
+void fxrx_pinned_free(void *p) { if (p) (void)hipHostFree(p); }
 
 static int make_slot(fxrx_ctx_s *c)
 {
@@ -674,10 +684,16 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     Slot &sl = *c->slots[c->head];
     sl.out.clear(); sl.timing = fxrx_timing{};
     sl.kept_hops = sl.kept_cheap = sl.kept_vhops = sl.kept_vfail = sl.kept_repairs = 0;
+    const unsigned noskip_before = c->noskip_left;
     sl.force_noskip = c->noskip_left > 0; if (c->noskip_left) c->noskip_left--;
     sl.seq = c->seq;
     sl.x.assign(NS, nullptr); sl.n.assign(n_samples, n_samples + NS); sl.snap.assign(NS, StreamSnap{});
     if (sl.d_in.size() < NS) sl.d_in.resize(NS);
+    // A submit that fails leaves the context as it found it: per-stream positions, freshness and tail bounds are restored, so
+    // that the next block -- the same samples again, or others -- continues from the state before the call.  (Caller-recoverable
+    // failures happen before anything is launched: argument checks, arena sizing, allocations.)
+    struct Undo { fxrx_ctx_s *c; std::vector<StreamState> st; unsigned noskip; bool armed = true;
+                  ~Undo() { if (armed) { c->st = st; c->noskip_left = noskip; } } } undo{ c, c->st, noskip_before };
     uint64_t total_new = 0;
     for (unsigned s = 0; s < NS; s++) {
         StreamState &S = c->st[s];
@@ -695,8 +711,10 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         S.carry_bound = std::min<int64_t>(S.carry_cap, sl.snap[s].carry_bound + (int64_t)nn);
     }
     sl.timing.samples = total_new;
+    if (c->debug_fail_submit) { c->debug_fail_submit--; set_err("fxrx_submit: injected failure (fxrx_debug_fail)"); return FXRX_ERR_STATE; }
     int r = enqueue_block(c, sl);
     if (r) return r;
+    undo.armed = false;
     c->seq++;
     sl.busy = true;
     c->head = (c->head + 1) % nslots; c->inflight++;
@@ -883,16 +901,68 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
     return 0;
 }
 
+// A block that cannot be completed takes the blocks in flight behind it along (they continue its streams, or at least share its
+// arenas' fate): everything in flight is dropped, the slots' device-side counters are cleared, and every stream restarts from a
+// freshly reset synchroniser with its next block -- sample positions keep counting, the dropped samples are simply never
+// searched.  The context stays usable (unless the HIP runtime itself is gone: then every later call fails the same way).
+static void discard_inflight(fxrx_ctx_s *c)
+{
+    const std::string keep = g_err;
+    sync_all(c);
+    const unsigned nslots = c->depth + 1;
+    while (c->inflight) {
+        Slot &s = *c->slots[c->tail];
+        s.busy = false; s.out.clear();
+        c->tail = (c->tail + 1) % nslots; c->inflight--; c->discarded++;
+    }
+    for (auto &s : c->slots) {
+        if (s->d_hdr.p) (void)hipMemset(s->d_hdr.p, 0, 2 * sizeof(FxBlockHdr));
+        if (s->d_plan_ws.p) (void)hipMemset(s->d_plan_ws.p, 0, fx_plan_ws_words() * sizeof(uint32_t));
+        if (s->h_hdr.p) std::memset(s->h_hdr.p, 0, sizeof(FxBlockHdr));
+    }
+    for (auto &S : c->st) { S.fresh_start = true; S.carry_bound = 0; }
+    c->last = nullptr; c->prev_chain = nullptr;
+    for (auto &e : c->carry_reader) e = nullptr;
+    set_err(keep);
+}
+
+static int collect_block(fxrx_ctx_s *c);
+
 int fxrx_collect(fxrx_ctx *c)
 {
     if (!c) return FXRX_ERR_ARG;
     if (!c->inflight) { set_err("fxrx_collect: nothing in flight"); return FXRX_ERR_STATE; }
+    const int r = collect_block(c);
+    if (r < 0) discard_inflight(c);
+    return r;
+}
+
+int fxrx_ready(const fxrx_ctx *c)
+{
+    if (!c) return FXRX_ERR_ARG;
+    if (!c->inflight) return 0;
+    const hipError_t e = hipEventQuery(c->slots[c->tail]->ev[8]);
+    return e == hipSuccess ? 1 : (e == hipErrorNotReady ? 0 : FXRX_ERR_HIP);
+}
+
+unsigned int fxrx_inflight(const fxrx_ctx *c) { return c ? c->inflight : 0; }
+
+int fxrx_debug_fail(fxrx_ctx *c, unsigned int submits, unsigned int collects)
+{
+    if (!c) return FXRX_ERR_ARG;
+    c->debug_fail_submit = submits; c->debug_fail_collect = collects;
+    return 0;
+}
+
+static int collect_block(fxrx_ctx_s *c)
+{
     HIP_OK(hipSetDevice(c->cfg.device));
     const unsigned NS = c->cfg.n_streams;
     const unsigned nslots = c->depth + 1;
     Slot &sl = *c->slots[c->tail];
     const auto tw = std::chrono::steady_clock::now();
     HIP_OK(hipEventSynchronize(sl.ev[8]));
+    if (c->debug_fail_collect) { c->debug_fail_collect--; set_err("fxrx_collect: injected failure (fxrx_debug_fail)"); return FXRX_ERR_STATE; }
     {
         const uint32_t flags = sl.h_hdr.p->flags;
         if (flags & FX_BLK_CHAIN_FULL) { set_err("fxrx_collect: chain table overflow (internal sizing error)"); return FXRX_ERR_STATE; }
@@ -939,7 +1009,7 @@ int fxrx_collect(fxrx_ctx *c)
     }
     c->frames_hint = h.n_frames; c->plain_hint = h.n_dec_plain; c->batch_hint = h.n_dec_batch; c->vb_items_hint = h.n_vb_items;
     c->mf_items_hint = h.n_mfblk; c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
-    c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - c->rs_hint / 8;      // (fades out over a few dozen blocks without such frames)
+    c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - std::min<uint64_t>(c->rs_hint, std::max<uint64_t>(1, c->rs_hint / 8));   // (fades out, to zero, over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
     float ms = 0;

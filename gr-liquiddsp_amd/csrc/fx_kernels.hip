@@ -26,6 +26,7 @@
 // No MFMA anywhere: nothing on this path is a dense contraction.  Taps, windows, spectra and the
 // FFT exchange buffers live in LDS; IQ is read from HBM as coalesced float2.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include "fx_device.h"
 
 // 8 waves: the 49 CFO-sweep transforms of a hop take 7 rounds instead of 13.  The 512-sample window is still
@@ -3386,6 +3387,57 @@ extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxT
                                       const uint8_t *head_idx, const uint8_t *pay_idx, const FxTxTables *T, float2 *out)
 {
     hipLaunchKernelGGL(fx_txgen_kernel, dim3(ntiles), dim3(TX_TILE), 0, st, jobs, tile_job, tile_n0, head_idx, pay_idx, T, out);
+    return hipGetLastError();
+}
+
+// ----- synthetic channel (test / bench signal source): carrier offset and phase by the closed-form 32-bit NCO the
+// receiver uses, gain, and white Gaussian noise from a counter-based generator -- Philox-4x32-10 keyed by the stream's seed,
+// counter = sample pair index, Box-Muller on its four words -- so that every sample of every stream is reproducible from
+// (seed, index) alone, on any grid.  One thread per pair of samples (16-byte accesses); grid.y = stream.
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 k)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const uint32_t h0 = __umulhi(0xD2511F53u, c.x), l0 = 0xD2511F53u * c.x, h1 = __umulhi(0xCD9E8D57u, c.z), l1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(h1 ^ c.y ^ k.x, l1, h0 ^ c.w ^ k.y, l0);
+        k.x += 0x9E3779B9u; k.y += 0xBB67AE85u;
+    }
+    return c;
+}
+__device__ __forceinline__ float2 gauss_pair(uint32_t a, uint32_t b)
+{
+    const float u1 = ((float)(a >> 8) + 1.0f) * 5.9604645e-8f;            // (0, 1]
+    const float u2 = (float)(b >> 8) * 5.9604645e-8f;                     // [0, 1)
+    const float r = sqrtf(-2.0f * logf(u1));
+    float sn, cs; sincosf(6.28318531f * u2, &sn, &cs);
+    return make_float2(r * cs, r * sn);
+}
+extern "C" __global__ __launch_bounds__(256)
+void fx_channel_kernel(float2 *x, unsigned long long n_per_stream, const FxChannel *chs, const FxTxTables *T)
+{
+    const FxChannel ch = chs[blockIdx.y];
+    float4 *xs = reinterpret_cast<float4 *>(x + (size_t)blockIdx.y * n_per_stream);     // (n_per_stream is even: 16-byte aligned)
+    const unsigned long long npair = n_per_stream / 2;
+    const uint2 key = make_uint2((uint32_t)ch.seed, (uint32_t)(ch.seed >> 32));
+    for (unsigned long long p = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; p < npair; p += (unsigned long long)gridDim.x * blockDim.x) {
+        float4 v = xs[p];
+        const uint4 rnd = philox4x32_10(make_uint4((uint32_t)p, (uint32_t)(p >> 32), 0u, 0u), key);
+        const float2 w0 = gauss_pair(rnd.x, rnd.y), w1 = gauss_pair(rnd.z, rnd.w);
+        float c0, s0, c1, s1;
+        const uint32_t th = ch.th0 + ch.dl * (uint32_t)(2ull * p);
+        sincos_u32(th, T->sc, c0, s0); sincos_u32(th + ch.dl, T->sc, c1, s1);
+        float4 y;
+        y.x = fmaf(ch.sigma, w0.x, ch.gain * (v.x * c0 - v.y * s0)); y.y = fmaf(ch.sigma, w0.y, ch.gain * (v.x * s0 + v.y * c0));
+        y.z = fmaf(ch.sigma, w1.x, ch.gain * (v.z * c1 - v.w * s1)); y.w = fmaf(ch.sigma, w1.y, ch.gain * (v.z * s1 + v.w * c1));
+        xs[p] = y;
+    }
+}
+extern "C" hipError_t fx_launch_channel(hipStream_t st, float2 *x, unsigned n_streams, unsigned long long n_per_stream, const FxChannel *chs, const FxTxTables *T)
+{
+    if (n_streams == 0 || n_per_stream == 0) return hipSuccess;
+    const unsigned long long npair = n_per_stream / 2;
+    const unsigned gx = (unsigned)std::min<unsigned long long>((npair + 255) / 256, 4096ull);
+    hipLaunchKernelGGL(fx_channel_kernel, dim3(gx, n_streams), dim3(256), 0, st, x, n_per_stream, chs, T);
     return hipGetLastError();
 }
 

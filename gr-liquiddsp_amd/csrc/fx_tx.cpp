@@ -8,6 +8,7 @@
 // encoded by fx_codec.hpp on host threads instead and join at the symbol-index stage.  Output is bit-identical to the host generator behind flexframegen_* (fx_dropin.cpp) and to the oracle's
 // fxr_gen_frame.
 #include <hip/hip_runtime.h>
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <algorithm>
@@ -24,6 +25,7 @@ extern "C" hipError_t fx_launch_txgen(unsigned ntiles, hipStream_t st, const FxT
                                       const uint8_t *head_idx, const uint8_t *pay_idx, const FxTxTables *T, float2 *out);
 extern "C" hipError_t fx_launch_txenc(unsigned njobs, hipStream_t st, const FxTxEncJob *jobs, const uint8_t *pay, const uint32_t *perm_arena,
                                       uint8_t *bufA, uint8_t *bufB, uint8_t *pay_idx, const FxTxTables *T);
+extern "C" hipError_t fx_launch_channel(hipStream_t st, float2 *x, unsigned n_streams, unsigned long long n_per_stream, const FxChannel *chs, const FxTxTables *T);
 extern "C" void fxrx_set_error(const char *msg);       // fx_host.cpp: thread-local message behind fxrx_last_error()
 
 namespace {
@@ -39,7 +41,7 @@ struct fxtx_ctx_s {
     hipStream_t stream = nullptr;
     Dev<FxTxTables> d_tab; Dev<uint8_t> d_idx; Dev<FxTxJob> d_jobs; Dev<uint32_t> d_tiles;
     // packet encoder on the GPU: payload bytes, scratch, interleaver gather tables (one per coded length, append-only)
-    Dev<uint8_t> d_pay, d_bufA, d_bufB; Dev<FxTxEncJob> d_ejobs; Dev<uint32_t> d_perm;
+    Dev<uint8_t> d_pay, d_bufA, d_bufB; Dev<FxTxEncJob> d_ejobs; Dev<uint32_t> d_perm; Dev<FxChannel> d_chan;
     std::map<uint32_t, uint32_t> perm_off; std::vector<uint32_t> perm_host; size_t perm_uploaded = 0;
     bool host_encode_only = false;       // FXTX_HOST_ENCODE=1: every frame's packet encoding on the host
 };
@@ -200,6 +202,27 @@ int fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, 
     ok = ok && fx_launch_txgen((unsigned)nt, c->stream, c->d_jobs.p, c->d_tiles.p, c->d_tiles.p + nt, c->d_idx.p, c->d_idx.p, c->d_tab.p, (float2 *)out_device) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;       // the staging vectors above are pageable and die with this call
     if (!ok) { fxrx_set_error(std::string("fxtx_generate: ") .append(hipGetErrorString(hipGetLastError())).c_str()); return FXRX_ERR_HIP; }
+    return 0;
+}
+
+// The channel of SURVEY 8(d) on the device: stream s = samples [s n_per_stream, (s + 1) n_per_stream) of iq_device, turned
+// by its carrier offset and phase, scaled, and given white Gaussian noise (fx_channel_kernel).  Synchronous.
+int fxtx_apply_channel(fxtx_ctx *c, void *iq_device, unsigned int n_streams, unsigned long long n_per_stream, const fxtx_channel *ch)
+{
+    if (!c || !iq_device || (!ch && n_streams)) { fxrx_set_error("fxtx_apply_channel: null argument"); return FXRX_ERR_ARG; }
+    if (n_per_stream & 1ull) { fxrx_set_error("fxtx_apply_channel: n_per_stream must be even"); return FXRX_ERR_ARG; }
+    if (n_streams > 65535u) { fxrx_set_error("fxtx_apply_channel: at most 65535 streams per call"); return FXRX_ERR_ARG; }
+    if (hipSetDevice(c->device) != hipSuccess) { fxrx_set_error("hipSetDevice failed"); return FXRX_ERR_HIP; }
+    std::vector<FxChannel> h(n_streams);
+    auto units = [](double rad) { return (uint32_t)(long long)std::nearbyint(rad * (4294967296.0 / 6.283185307179586)); };
+    for (unsigned s = 0; s < n_streams; s++) {
+        h[s].th0 = units(ch[s].phase); h[s].dl = units(ch[s].cfo); h[s].gain = ch[s].gain; h[s].sigma = ch[s].sigma; h[s].seed = ch[s].seed;
+    }
+    bool ok = c->d_chan.reserve(n_streams ? n_streams : 1);
+    ok = ok && hipMemcpyAsync(c->d_chan.p, h.data(), n_streams * sizeof(FxChannel), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    ok = ok && fx_launch_channel(c->stream, (float2 *)iq_device, n_streams, n_per_stream, c->d_chan.p, c->d_tab.p) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+    if (!ok) { fxrx_set_error(std::string("fxtx_apply_channel: ").append(hipGetErrorString(hipGetLastError())).c_str()); return FXRX_ERR_HIP; }
     return 0;
 }
 

@@ -84,12 +84,62 @@ class TxContext:
         if r != 0:
             raise RuntimeError("fxtx_generate: " + self.L.fxrx_last_error().decode())
 
+    def channel(self, iq_ptr, n_streams, n_per_stream, chans):
+        """chans: per stream (cfo rad/sample, phase rad, gain, sigma per real dimension, seed) -- applied in place on the device."""
+        arr = (_ffi.TxChannel * n_streams)(*[_ffi.TxChannel(float(c[0]), float(c[1]), float(c[2]), float(c[3]), int(c[4])) for c in chans])
+        r = self.L.fxtx_apply_channel(self.h, C.c_void_p(int(iq_ptr)), int(n_streams), int(n_per_stream), arr)
+        if r != 0:
+            raise RuntimeError("fxtx_apply_channel: " + self.L.fxrx_last_error().decode())
+
     def close(self):
         if getattr(self, "h", None):
             self.L.fxtx_destroy(self.h)
             self.h = None
 
     __del__ = close
+
+
+def synth_streams_device(n_streams, n_samples, first_stream_id=0, props=None, payload_len=1024, gap=256, snr_db=20.0, device=0, tx=None,
+                         streams_per_call=64):
+    """n_streams DISTINCT synthetic IQ streams of n_samples each, generated on the GPU (fxtx_generate + fxtx_channel) straight
+    into one device tensor of shape (n_streams, n_samples), complex64 -- the SURVEY 8(d) workload without the host ever
+    holding a stream: frames back to back with `gap` zero samples, per-stream payload bytes MT19937(0x5EED + id), per-stream
+    channel draws MT19937(0xC0FFEE + id): CFO ~ U(-0.05, 0.05) rad/sample, phase ~ U(-pi, pi), delay ~ U(-0.5, 0.5) sample,
+    AWGN at Es/N0 = snr_db from the device's counter-based generator (seed = id).  props(stream_id) -> dict with any of
+    mod, fec0, fec1, check, payload_len, snr_db (per-stream frame properties: the mod/FEC sweep of BASELINE config 5).
+    Returns (tensor, injected) with injected[s] = [(start sample, payload bytes), ...]."""
+    import torch
+    own = tx is None
+    tx = TxContext(device) if own else tx
+    out = torch.zeros((n_streams, n_samples), dtype=torch.complex64, device="cuda:%d" % device)
+    torch.cuda.synchronize(device)
+    injected, chans = [], []
+    for s0 in range(0, n_streams, streams_per_call):
+        frames = []
+        for s in range(s0, min(n_streams, s0 + streams_per_call)):
+            sid = first_stream_id + s
+            pr = dict(mod=2, fec0=11, fec1=1, check=CRC_24, payload_len=payload_len, snr_db=snr_db)
+            if props is not None:
+                pr.update(props(sid))
+            prng = np.random.RandomState((0x5EED + sid) & 0x7FFFFFFF)
+            crng = np.random.RandomState((0xC0FFEE + sid) & 0x7FFFFFFF)
+            cfo, phase, delay = crng.uniform(-0.05, 0.05), crng.uniform(-np.pi, np.pi), crng.uniform(-0.5, 0.5)
+            flen = tx.frame_len(dict(payload=np.zeros(pr["payload_len"], np.uint8), mod=pr["mod"], fec0=pr["fec0"], fec1=pr["fec1"], check=pr["check"]))
+            nfr = max(0, (n_samples + gap) // (flen + gap))
+            pls = prng.randint(0, 256, (nfr, pr["payload_len"])).astype(np.uint8)
+            mine = []
+            for k in range(nfr):
+                p = k * (flen + gap)
+                frames.append(dict(payload=pls[k], mod=pr["mod"], fec0=pr["fec0"], fec1=pr["fec1"], check=pr["check"], dt=delay,
+                                   offset=s * n_samples + p))
+                mine.append((p, pls[k].tobytes()))
+            injected.append(mine)
+            chans.append((cfo, phase, 1.0, np.sqrt(0.5 * 10.0 ** (-pr["snr_db"] / 10.0)), sid))
+        tx.generate(frames, out.data_ptr(), n_streams * n_samples)
+    tx.channel(out.data_ptr(), n_streams, n_samples, chans)
+    if own:
+        tx.close()
+    return out, injected
 
 
 def synth_stream(n_samples, stream_id=0, mod=2, fec0=11, fec1=1, check=CRC_24, payload_len=1024, gap=256,

@@ -69,16 +69,24 @@ void flexframesync_destroy(flexframesync q);
  * Buffers passed to the callback stay valid until the next call on the same handle. */
 void flexframesync_execute(flexframesync q, fx_complex *x, unsigned int n);
 void flexframesync_reset(flexframesync q);
-/* extensions (additive): process whatever is queued now; tune the queue length (samples). */
+/* extensions (additive).  Samples are collected in page-locked buffers of `block` samples (default 2^20; FXRX_SYNC_BLOCK) and
+ * run through the GPU as consecutive blocks of one continuing stream, up to FXRX_SYNC_DEPTH (default 3) of them in flight while
+ * the next buffer fills: flexframesync_execute never waits for the GPU unless all of those are still busy.  Frames therefore
+ * reach the callback in order, one per call, between one and `depth` + 1 blocks after their last sample was handed in.
+ * fxrx_sync_flush: run whatever is queued now and wait for everything in flight (frames are then pending: n = 0 calls
+ * deliver them).  fxrx_sync_set_block: flushes, then changes the block length. */
 void fxrx_sync_flush(flexframesync q);
 void fxrx_sync_set_block(flexframesync q, unsigned int samples);
 void fxrx_sync_set_threshold(flexframesync q, float threshold);
 void fxrx_sync_set_equalizer(flexframesync q, int on);   /* re-creates the context like fxrx_sync_set_threshold */
 void fxrx_sync_set_soft(flexframesync q, int on);        /* likewise: soft-decision payload decoding */
 unsigned int fxrx_sync_pending(flexframesync q);     /* completed frames not yet delivered */
-/* the liquid signatures return void: a block that failed on the GPU keeps its samples queued (they run again with the
- * next call), the text stays in fxrx_last_error(), one line goes to stderr and this counter goes up */
+/* the liquid signatures return void: when a block fails on the GPU its samples (and those of the blocks in flight with it) are
+ * dropped -- never fed twice --, the synchroniser restarts freshly reset behind the gap, the text stays in fxrx_last_error(),
+ * one line goes to stderr and this counter goes up */
 unsigned int fxrx_sync_errors(flexframesync q);
+struct fxrx_ctx_s;
+struct fxrx_ctx_s *fxrx_sync_context(flexframesync q);   /* the batched context underneath (tests, statistics) */
 
 /* m-sequence -- /root/reference/lib/frame_detector_cc_impl.cc:47,49,50,52 */
 typedef struct fxrx_mseq_s *msequence;
@@ -164,6 +172,9 @@ typedef struct fxrx_ctx_s fxrx_ctx;
 const char *fxrx_last_error(void);
 const char *fxrx_version(void);
 int         fxrx_device_count(void);
+/* page-locked host memory for input buffers: uploads from it run asynchronously (NULL + fxrx_last_error() on failure) */
+void       *fxrx_pinned_alloc(size_t bytes);
+void        fxrx_pinned_free(void *p);
 
 fxrx_ctx *fxrx_create(const fxrx_config *cfg);
 void      fxrx_destroy(fxrx_ctx *c);
@@ -190,6 +201,17 @@ int fxrx_result(const fxrx_ctx *c, unsigned int i, fxrx_frame *out);
 int fxrx_set_depth(fxrx_ctx *c, unsigned int depth);
 int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, int on_device);
 int fxrx_collect(fxrx_ctx *c);
+/* Failure semantics.  A failing fxrx_submit (bad arguments, a batch too large for the arenas, an allocation that fails) leaves
+ * the context exactly as it was: the same block, or another, can be submitted next and continues the streams from where they
+ * stood.  A failing fxrx_collect drops every block in flight (their samples are never searched) and restarts all streams
+ * from a freshly reset synchroniser with the next block submitted; sample positions keep counting.  Either way the context
+ * stays usable -- unless the HIP runtime itself reports errors, which every later call will report again. */
+/* 1: the oldest block in flight has finished (fxrx_collect will not wait), 0: not yet / nothing in flight, < 0: FXRX_ERR_* */
+int fxrx_ready(const fxrx_ctx *c);
+unsigned int fxrx_inflight(const fxrx_ctx *c);
+/* tests: make the next `submits` calls of fxrx_submit / `collects` calls of fxrx_collect fail (FXRX_ERR_STATE) after they have
+ * done their bookkeeping, to exercise the paths above */
+int fxrx_debug_fail(fxrx_ctx *c, unsigned int submits, unsigned int collects);
 /* diagnostic builds (-DFX_STAMPS) only: shader-clock deltas of the decode phases of payload job i */
 int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8]);
 int fxrx_debug_chain_stamps(const fxrx_ctx *c, uint32_t out[8]);  /* chain kernel phase clocks (stream 0) of the last collected block */
@@ -253,6 +275,14 @@ unsigned int fxtx_frame_len(const fxtx_frame *f);            /* samples the fram
  * synchronous (the frames are in the buffer when the call returns). */
 int          fxtx_generate(fxtx_ctx *c, const fxtx_frame *frames, unsigned int n_frames, void *out_device,
                            unsigned long long out_len);
+/* The synthetic channel of the test / bench source on the device, so that hundreds of distinct streams
+ * never exist on the host: stream s = samples [s n_per_stream, (s+1) n_per_stream) of iq_device becomes
+ * gain x[n] exp(j (phase + n cfo)) + noise, noise white Gaussian with standard deviation sigma per real dimension, drawn from
+ * a counter-based generator keyed by `seed` (every sample is a function of (seed, n) alone).  n_per_stream must be even.
+ * Synchronous; returns 0 or FXRX_ERR_*. */
+typedef struct { float cfo, phase, gain, sigma; unsigned long long seed; } fxtx_channel;
+int          fxtx_apply_channel(fxtx_ctx *c, void *iq_device, unsigned int n_streams, unsigned long long n_per_stream,
+                          const fxtx_channel *ch);
 
 #ifdef __cplusplus
 }

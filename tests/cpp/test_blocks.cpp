@@ -40,6 +40,7 @@ int main()
         in[0] = x.data() + i;
         if (rx->work(n, in, out) != n) { std::printf("FAIL work return\n"); return 1; }
     }
+    rx->flush();                                                     // (the stream ends here: run what is still queued)
     frame_detector_cc::sptr det = frame_detector_cc::make();
     std::vector<gr_complex> y(x.size()); gr_vector_void_star outs(1); outs[0] = y.data(); in[0] = x.data();
     det->work((int)x.size(), in, outs);

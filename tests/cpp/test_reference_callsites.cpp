@@ -170,12 +170,12 @@ int main(int argc, char **argv)
     }
     std::normal_distribution<float> nd(0.0f, 0.04f);
     for (size_t n = 0; n < x.size(); n++) x[n] = x[n] * std::polar(1.0f, -0.015f * (float)n + 0.2f) + gr_complex(nd(rng), nd(rng));
-    x.insert(x.end(), 70000, gr_complex(0, 0));                               // the drop-in runs 64 Ki-sample blocks: push the last one through
     while (x.size() % 256) x.push_back(gr_complex(0, 0));
 
     rx_calls rx;
     if (!rx.d_fs) { std::fprintf(stderr, "flexframesync_create failed: %s\n", fxrx_last_error()); return 2; }
     int consumed = rx.work((int)x.size(), x.data());
+    fxrx_sync_flush(rx.d_fs);                                                 // the stream ends here: the drop-in runs whole blocks, push the last one through
     gr_complex zero[256] = {};
     for (int k = 0; k < 64 && fxrx_sync_pending(rx.d_fs); k++) rx.work(256, zero);   // one frame per call, as the reference's loop drains them
 

