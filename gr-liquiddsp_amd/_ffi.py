@@ -105,6 +105,10 @@ def feed_lib():
         L = C.CDLL(os.path.join(CSRC, "libdropin_feed.so"))
         L.dropin_feed.restype = C.c_int
         L.dropin_feed.argtypes = [C.c_void_p, C.c_ulonglong, C.c_uint, C.c_uint, C.POINTER(DropinStats)]
+        L.dropin_feed_raw.restype = C.c_int
+        L.dropin_feed_raw.argtypes = [C.c_void_p, C.c_ulonglong, C.c_uint, C.POINTER(DropinStats)]
+        L.dropin_copy_ceiling.restype = C.c_double
+        L.dropin_copy_ceiling.argtypes = [C.c_void_p, C.c_ulonglong, C.c_uint, C.c_uint]
         L.dropin_feed_threads.restype = C.c_int
         L.dropin_feed_threads.argtypes = [C.POINTER(C.c_void_p), C.POINTER(C.c_ulonglong), C.c_uint, C.c_uint, C.POINTER(DropinStats)]
         _feed = L

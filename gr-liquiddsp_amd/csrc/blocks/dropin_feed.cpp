@@ -65,6 +65,65 @@ int dropin_feed(const float *iq, unsigned long long n_samples, unsigned items_pe
     return 0;
 }
 
+// The bare C boundary without the block shell's messages: flexframesync_execute(q, x, 256) over the buffer, a callback that
+// counts frames and hashes payload bytes where they lie (no copies) -- what the library itself costs behind the reference's
+// calling convention, apart from what the caller does with a frame.
+static int raw_cb(unsigned char *, int hv, unsigned char *p, unsigned int n, int pv, framesyncstats_s st, void *ud)
+{
+    dropin_stats *s = (dropin_stats *)ud;
+    s->frames++; s->constellation_syms += st.num_framesyms;
+    if (hv) {
+        s->header_valid++; s->payload_bytes += n; s->payload_valid += (uint64_t)(pv != 0); s->packet_infos++;
+        uint64_t h = s->payload_hash;
+        for (unsigned i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+        s->payload_hash = h;
+    }
+    return 0;
+}
+int dropin_feed_raw(const float *iq, unsigned long long n_samples, unsigned repeats, dropin_stats *out)
+{
+    using clk = std::chrono::steady_clock;
+    dropin_stats st{}; st.payload_hash = 14695981039346656037ull;
+    flexframesync q = flexframesync_create(raw_cb, &st);
+    if (!q) return -1;
+    const auto t0 = clk::now();
+    for (unsigned r = 0; r < (repeats ? repeats : 1u); r++) {
+        if (r) flexframesync_reset(q);
+        for (unsigned long long p = 0; p + 256 <= n_samples; p += 256) flexframesync_execute(q, (fx_complex *)(iq + 2 * p), 256);
+        fxrx_sync_flush(q);
+        while (fxrx_sync_pending(q)) flexframesync_execute(q, nullptr, 0);
+    }
+    st.seconds = std::chrono::duration<double>(clk::now() - t0).count();
+    st.errors = fxrx_sync_errors(q);
+    flexframesync_destroy(q);
+    *out = st;
+    return 0;
+}
+
+#ifndef DROPIN_NO_CEILING      /* (built without it against round 2's library, which has no fxrx_pinned_alloc) */
+// What the calling convention alone costs: the same stream in the same 256-sample pieces, each piece only copied into a page-locked
+// buffer of `block` samples (what any GPU implementation behind flexframesync_execute has to do with pageable caller memory
+// before it can upload).  Returns samples per second of that loop -- the ceiling of the drop-in boundary on this host.
+double dropin_copy_ceiling(const float *iq, unsigned long long n_samples, unsigned block, unsigned repeats)
+{
+    using clk = std::chrono::steady_clock;
+    fx_complex *buf = (fx_complex *)fxrx_pinned_alloc((size_t)block * sizeof(fx_complex));
+    if (!buf) return 0.0;
+    volatile size_t sink = 0;
+    const auto t0 = clk::now();
+    for (unsigned r = 0; r < (repeats ? repeats : 1u); r++) {
+        size_t fill = 0;
+        for (unsigned long long p = 0; p + 256 <= n_samples; p += 256) {
+            std::memcpy(buf + fill, iq + 2 * p, 256 * sizeof(fx_complex));
+            fill += 256; if (fill + 256 > block) { sink = sink + fill; fill = 0; }
+        }
+    }
+    const double dt = std::chrono::duration<double>(clk::now() - t0).count();
+    fxrx_pinned_free(buf);
+    return (double)(repeats ? repeats : 1u) * (double)(n_samples - n_samples % 256) / dt;
+}
+#endif
+
 // the same from `n_threads` threads at once, each with its own block instance (GNU Radio: one thread per block) and its own
 // buffer; stats[t] per thread.  Returns the number of threads that failed to make their block.
 int dropin_feed_threads(const float *const *iq, const unsigned long long *n_samples, unsigned n_threads, unsigned items_per_work, dropin_stats *stats)

@@ -222,8 +222,9 @@ struct BlockCodes {
             for (unsigned v = 1; v < 128 && k < 32; v++) if (__builtin_popcount(v) == 3) sd39_col[k++] = (uint8_t)v;
         }
         for (unsigned d = 0; d < 16; d++) {     // Hamming(7,4), systematic
-            unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
-            h74_enc[d] = (uint8_t)((d << 3) | ((d1 ^ d2 ^ d3) << 2) | ((d0 ^ d2 ^ d3) << 1) | (d0 ^ d1 ^ d3));
+            // liquid's fec_hamming74.c table [recalled]: [p1 p2 d1 p4 d2 d3 d4], d1 = the nibble's MSB
+            const unsigned d1 = (d >> 3) & 1, d2 = (d >> 2) & 1, d3 = (d >> 1) & 1, d4 = d & 1;
+            h74_enc[d] = (uint8_t)(((d1 ^ d2 ^ d4) << 6) | ((d1 ^ d3 ^ d4) << 5) | (d1 << 4) | ((d2 ^ d3 ^ d4) << 3) | (d2 << 2) | (d3 << 1) | d4);
         }
         for (unsigned r = 0; r < 128; r++) {
             unsigned best = 0, bd = 99;
@@ -259,8 +260,9 @@ struct BlockCodes {
         for (int a = 0; a < 24; a++) for (int b = a + 1; b < 24; b++) note((1u << a) | (1u << b));
         for (int a = 0; a < 24; a++) for (int b = a + 1; b < 24; b++) for (int c2 = b + 1; c2 < 24; c2++) note((1u << a) | (1u << b) | (1u << c2));
         for (unsigned d = 0; d < 16; d++) {
-            unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
-            unsigned c = (d << 4) | ((d1 ^ d2 ^ d3) << 3) | ((d0 ^ d2 ^ d3) << 2) | ((d0 ^ d1 ^ d3) << 1);
+            // liquid's fec_hamming84.c table [recalled]: [p1 p2 d1 p4 d2 d3 d4 p8], p8 = overall parity (00 d2 55 87 99 4b cc 1e e1 33 b4 66 78 aa 2d ff)
+            const unsigned d1 = (d >> 3) & 1, d2 = (d >> 2) & 1, d3 = (d >> 1) & 1, d4 = d & 1;
+            unsigned c = ((d1 ^ d2 ^ d4) << 7) | ((d1 ^ d3 ^ d4) << 6) | (d1 << 5) | ((d2 ^ d3 ^ d4) << 4) | (d2 << 3) | (d3 << 2) | (d4 << 1);
             c |= (unsigned)__builtin_popcount(c) & 1u;
             h84_enc[d] = (uint8_t)c;
         }

@@ -32,7 +32,7 @@ struct HeldFrame {
 
 constexpr unsigned kSyncBlockDefault = 1u << 20;    // samples per GPU block (fxrx_sync_set_block / FXRX_SYNC_BLOCK); see DESIGN.md section 7
 constexpr unsigned kSyncDepthDefault = 3;           // blocks in flight (FXRX_SYNC_DEPTH)
-constexpr unsigned kSyncPollEvery = 4096;           // samples between two looks at whether the oldest block has finished
+constexpr unsigned kSyncPollEvery = 1u << 15;       // samples between two looks at whether the oldest block has finished (an event query costs about as much as copying 4000 samples)
 
 }  // namespace
 

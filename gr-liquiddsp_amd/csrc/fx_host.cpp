@@ -46,7 +46,8 @@
 #include "fx_codec.hpp"
 
 extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
-                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total);
+                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total,
+                                     const uint32_t *n_list, uint32_t list_cap);
 extern "C" hipError_t fx_launch_seekverify(unsigned grid, hipStream_t st, const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results,
                                            FxFrame *frames, FxBlockHdr *hdr, const FxTables *T, uint32_t phase);
 extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_t n_jobs_total,
@@ -54,7 +55,7 @@ extern "C" hipError_t fx_launch_chain(unsigned mode, int eq, unsigned nstreams, 
                                       FxBlockHdr *hdr, uint32_t force_slow, const FxTables *T);
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
                                           const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair,
-                                          FxWalkJob *jobs_rw, uint32_t *req_list);
+                                          FxWalkJob *jobs_rw, uint32_t *req_list, uint32_t *stat, uint32_t pass);
 extern "C" hipError_t fx_launch_plan(hipStream_t st, unsigned grid, const FxStreamDesc *streams, uint32_t nstreams, uint32_t detect, uint32_t eq, uint32_t vb_blk, const FxFrame *chain,
                                      const uint32_t *chain_count, uint32_t *stream_base, FxPayJob *pjobs, FxOutRec *recs, uint32_t *mf_job, uint32_t *mf_c0, uint32_t mf_cap,
                                      uint32_t *pll_list, uint32_t *dec_list, uint32_t list_cap, uint32_t *vb_items, uint32_t vb_cap, FxBlockHdr *hdr, FxBlockHdr *hdr_pay,
@@ -160,6 +161,7 @@ struct Slot {
     DevBuf<uint32_t> d_chain_count, d_stream_base, d_mf_job, d_mf_c0, d_pll_list, d_dec_list, d_vb_items;
     DevBuf<uint32_t> d_plan_ws;              // plan kernels: look-back state, list counts and cursors (zero between blocks)
     DevBuf<uint32_t> d_req;                  // repair rounds: segments to be walked again from their true start state
+    DevBuf<uint32_t> d_cstat;                // in-chain repair round: per stream 1 stitched | 2 pending (segments queued) | 3 left to fxrx_collect
     DevBuf<uint8_t> d_vb_vec;                // batch Viterbi: metric differences at the start and end of every trellis block
     DevBuf<unsigned long long> d_vb_dw;      // its decision words, step-major within the 64 work items of a wave
     DevBuf<uint32_t> d_vb_st;                // traceback states and flags per work item
@@ -200,6 +202,7 @@ struct fxrx_ctx_s {
     uint64_t plain_hint = 0, batch_hint = 0, vb_items_hint = 0, vb_steps_hint = 0, vb_want_hint = 0;   // likewise: frames of the wave-per-frame / batch decoders, trellis blocks, trellis steps
     bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
+    bool inchain_repair = true;          // FXRX_INCHAIN_REPAIR=0: no repair round within the chain (everything that takes a walk waits for fxrx_collect)
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
     hipStream_t st_chain = nullptr;      // highest priority: the state-dependent stretch of continuing blocks (true walkers, their verification, chain kernel)
     uint32_t verify_per_cu = 4;          // FXRX_VERIFY_PER_CU: workgroups of the seek verifier per CU (they stride over the runs)
@@ -348,6 +351,7 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_INCHAIN_REPAIR")) c->inchain_repair = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VERIFY_PER_CU")) c->verify_per_cu = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_MF_PER_CU")) c->mf_per_cu = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -516,7 +520,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     sl.o_list = o_list; sl.o_streams = o_streams;
     const uint32_t list_cap = chain_slots + 64 * FX_PLL_CLASSES;
     if (sl.hp_desc.reserve(desc_bytes) || sl.d_desc.reserve(desc_bytes) || sl.d_wres.reserve(NJ + NS) || sl.d_frames.reserve(frame_slots) ||
-        sl.d_runs.reserve(sl.run_cap) || sl.d_req.reserve(2 * NJ + 16) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
+        sl.d_runs.reserve(sl.run_cap) || sl.d_req.reserve(2 * NJ + 16) || sl.d_cstat.reserve(NS) || sl.d_chain.reserve(chain_slots) || sl.d_chain_count.reserve(NS) || sl.d_stream_base.reserve(NS + 1) ||
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
         sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(4 * (size_t)list_cap)) return FXRX_ERR_HIP;
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
@@ -544,7 +548,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     // ---- 3. the chain, front part: walkers and seek verification ----
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
     HIP_OK(hipEventRecord(sl.ev[0], st));
-    HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
+    HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ, nullptr, 0u));
     // the true walkers of continuing streams read the state the previous block's chain kernel leaves.  What the speculative
     // walkers skipped is verified before that wait -- it does not depend on the state --, so that the chain of dependencies
     // from one block's chain kernel to the next one's is just: true walkers, their few verification runs, chain kernel
@@ -567,7 +571,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         cst = c->st_chain;
         HIP_OK(hipStreamWaitEvent(cst, sl.ev[9], 0));
         if (c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
-        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), cst, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ));
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), cst, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ, nullptr, 0u));
     }
     HIP_OK(hipEventRecord(sl.ev[1], cst));
     if (verify)
@@ -597,8 +601,23 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
     if (chain_mode == kChainFull)
         HIP_OK(fx_launch_chain(mode, c->cfg.equalizer ? 1 : 0, NS, st, d_streams, d_jobs, (uint32_t)sl.NJ, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, sl.d_runs.p, sl.run_cap,
                                hdr, c->chain_slow ? 1u : 0u, c->d_tables));
-    else if (chain_mode == kChainFast)
-        HIP_OK(fx_launch_chainfast(NS, chain_st ? chain_st : st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u, nullptr, nullptr));
+    else if (chain_mode == kChainFast) {
+        // stitch; one repair round within the chain for what only takes a walk from a hand-off state (a hand-off target missing
+        // from the next list, a skipped hop on which the exact detector fires): its walkers read the number of queued segments
+        // on the device -- normally none: two launches that leave at once --; stitch the streams concerned again.  Whatever
+        // is still open after that is flagged and mended when the block is collected (repair_and_replay).
+        hipStream_t cs = chain_st ? chain_st : st;
+        FxWalkJob *d_jobs_rw = reinterpret_cast<FxWalkJob *>(sl.d_desc.p);
+        const uint32_t req_cap = (uint32_t)(2 * sl.NJ + 16);
+        if (c->chain_slow || !c->inchain_repair)
+            HIP_OK(fx_launch_chainfast(NS, cs, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u, nullptr, nullptr, nullptr, 0u));
+        else {
+            HIP_OK(fx_launch_chainfast(NS, cs, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, 0u, d_jobs_rw, sl.d_req.p, sl.d_cstat.p, 1u));
+            HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)std::min<size_t>(2 * sl.NJ, 64), cs, d_jobs, sl.d_req.p, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, hdr,
+                                  c->d_tables, 1, (uint32_t)sl.NJ, &hdr->n_repair_req, req_cap));
+            HIP_OK(fx_launch_chainfast(NS, cs, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, 0u, nullptr, nullptr, sl.d_cstat.p, 2u));
+        }
+    }
     // (kChainDone: the repair rounds have stitched the block already)
     HIP_OK(hipEventRecord(sl.ev[3], chain_mode == kChainFast && chain_st ? chain_st : st));
     if (chain_mode == kChainFast && chain_st && chain_st != st) HIP_OK(hipStreamWaitEvent(st, sl.ev[3], 0));   // back onto the block's own stream
@@ -748,7 +767,7 @@ static int repair_rounds(fxrx_ctx_s *c, Slot &sl)
     FxBlockHdr *hdr = sl.d_hdr.p;
     for (int round = 0; round < 64; round++) {
         HIP_OK(hipMemsetAsync(hdr, 0, sizeof(FxBlockHdr), st));
-        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, 0u, d_jobs, sl.d_req.p));
+        HIP_OK(fx_launch_chainfast(NS, st, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, 0u, d_jobs, sl.d_req.p, nullptr, 0u));
         FxBlockHdr hh;
         HIP_OK(hipMemcpyAsync(&hh, hdr, sizeof hh, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
@@ -763,7 +782,7 @@ static int repair_rounds(fxrx_ctx_s *c, Slot &sl)
             for (uint32_t r : req) if ((r & 0x80000000u) && (r & 0x7fffffffu) < sl.NJ) c->st[hj[r & 0x7fffffffu].stream].noskip_left = 32;
         }
         HIP_OK(hipMemsetAsync(hdr, 0, sizeof(FxBlockHdr), st));
-        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, hh.n_repair_req, st, d_jobs, sl.d_req.p, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, hdr, c->d_tables, 1, (uint32_t)sl.NJ));
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, hh.n_repair_req, st, d_jobs, sl.d_req.p, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, hdr, c->d_tables, 1, (uint32_t)sl.NJ, nullptr, 0u));
         HIP_OK(hipMemcpyAsync(&hh, hdr, sizeof hh, hipMemcpyDeviceToHost, st));
         HIP_OK(hipStreamSynchronize(st));
         sl.kept_hops += hh.hops; sl.kept_cheap += hh.hops_cheap; sl.kept_repairs += hh.walk_jobs_run ? hh.walk_jobs_run : 0;
@@ -971,6 +990,14 @@ static int collect_block(fxrx_ctx_s *c)
         if (flags & (FX_BLK_CARRY_OVERFLOW | FX_BLK_NEEDS_REPAIR)) { int r = repair_and_replay(c, sl); if (r) return r; }
     }
     if (c->cfg.mode != FXRX_MODE_DETECTOR) { int r = finish_decode(c, sl); if (r) return r; }
+    if (sl.h_hdr.p->n_repair_req && sl.h_hdr.p->verify_failures) {
+        // the chain mended something by itself: streams in which a skipped hop fired are walked with the exact detector on every
+        // hop for their next blocks (the list says which; a rare, small copy)
+        std::vector<uint32_t> req(std::min<size_t>(sl.h_hdr.p->n_repair_req, 2 * sl.NJ + 16));
+        HIP_OK(hipMemcpy(req.data(), sl.d_req.p, req.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        const FxWalkJob *hj = reinterpret_cast<const FxWalkJob *>(sl.hp_desc.p);
+        for (uint32_t r : req) if ((r & 0x80000000u) && (r & 0x7fffffffu) < sl.NJ) c->st[hj[r & 0x7fffffffu].stream].noskip_left = 32;
+    }
     sl.timing.host_collectwait_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw).count();
     const FxBlockHdr &h = *sl.h_hdr.p;
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
@@ -1022,7 +1049,7 @@ static int collect_block(fxrx_ctx_s *c)
         (void)hipEventElapsedTime(&ms, sl.ev[6], sl.ev[7]); t.paydec_ms = ms;
     }
     t.total_ms = t.walk_ms + t.seekverify_ms + t.chain_ms + t.paymf_ms + t.paypll_ms + t.paydec_ms;
-    t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs + sl.kept_repairs; t.frames = h.n_frames;
+    t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs + sl.kept_repairs + h.n_repair_req; t.frames = h.n_frames;
     t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops + sl.kept_vhops; t.verify_failures = h.verify_failures + sl.kept_vfail;
     t.host_submit_ms = sl.host_submit_ms; t.host_walkwait_ms = 0.0; t.walk_mode = sl.any_late ? 1 : 0; t.replays = c->replays + c->repairs_host;
     t.vb_blocks = h.n_vb_items; t.vb_repairs = vb_rep; t.late_decodes = c->late_decodes; t.vb_fallbacks = h.n_vb_fallback;

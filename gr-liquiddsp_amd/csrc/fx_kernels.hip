@@ -819,26 +819,46 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
 template <int MODE, int WW, bool EQ, bool EXT = false>
 __global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
 void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
-                    FxBlockHdr *hdr, const FxTables *T, uint32_t n_jobs_total)
+                    FxBlockHdr *hdr, const FxTables *T, uint32_t n_jobs_total, const uint32_t *n_list, uint32_t list_cap)
 {
     __shared__ WalkLdsT<WW> L;
-    const uint32_t ji = job_list[blockIdx.x] & 0x7fffffffu;
-    const FxWalkJob job = jobs[ji];
     const int tid = threadIdx.x, lane = tid & 63;
+    if constexpr (EXT) {
+        // the repair round enqueued with the block (fx_host.cpp:enqueue_back): how many segments are queued is only known on the
+        // device -- usually none, and the workgroups leave at once; else they stride over the list
+        if (n_list && blockIdx.x >= min(*n_list, list_cap)) return;
+    }
     float2 twA[7], twB[7];
 #pragma unroll
     for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
     for (int i = tid; i < FX_NFFT; i += 64 * WW) L.S[i] = T->S[i];
+    if constexpr (EXT) {
+        if (n_list) {
+            const uint32_t nreq = min(*n_list, list_cap);
+            for (uint32_t i = blockIdx.x; i < nreq; i += gridDim.x) {
+                const uint32_t ji = job_list[i] & 0x7fffffffu;
+                const FxWalkJob job = jobs[ji];
+                walk_run<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
+                __syncthreads();
+            }
+            return;
+        }
+    }
+    const uint32_t ji = job_list[blockIdx.x] & 0x7fffffffu;
+    const FxWalkJob job = jobs[ji];
     walk_run<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
 }
 
 // (the equaliser stage is a compile-time variant of the flex_rx walker: the default instance carries none of its code)
+// ext: the walks of a repair round (they may carry on into the segments behind theirs); n_list (ext only): the number of queued
+// segments is read from there on the device and `njobs` workgroups stride over them (list_cap bounds the count)
 extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipStream_t st, const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results,
-                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total)
+                                     FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, int ext, uint32_t n_jobs_total,
+                                     const uint32_t *n_list, uint32_t list_cap)
 {
     if (njobs == 0) return hipSuccess;
-#define FX_WALK_LAUNCH(M, W, E, X) hipLaunchKernelGGL((fx_walk_kernel<M, W, E, X>), dim3(njobs), dim3(64 * W), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T, n_jobs_total)
-    if (mode == FX_MODE_DETECT) FX_WALK_LAUNCH(FX_MODE_DETECT, FX_DETECT_WAVES, false, false);
+#define FX_WALK_LAUNCH(M, W, E, X) hipLaunchKernelGGL((fx_walk_kernel<M, W, E, X>), dim3(njobs), dim3(64 * W), 0, st, jobs, job_list, results, frames, runs, run_cap, hdr, T, n_jobs_total, n_list, list_cap)
+    if (mode == FX_MODE_DETECT) { if (ext) FX_WALK_LAUNCH(FX_MODE_DETECT, FX_DETECT_WAVES, false, true); else FX_WALK_LAUNCH(FX_MODE_DETECT, FX_DETECT_WAVES, false, false); }
     else if (ext) { if (eq) FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, true, true); else FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, false, true); }
     else if (eq) FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, true, false);
     else FX_WALK_LAUNCH(FX_MODE_FLEXRX, FX_FLEX_WAVES, false, false);
@@ -1150,42 +1170,53 @@ __device__ __forceinline__ bool chain_state_in(const FxStreamDesc &sd, uint32_t 
 // without a chain and without a state (FX_BLK_NEEDS_REPAIR): fxrx_collect then runs fx_chain_kernel -- the full-size one,
 // which can walk -- for the block and enqueues the blocks behind it again.
 #define CHAINFAST_THREADS 256
+// In-chain repair round (fx_host.cpp:enqueue_back): pass 1 is this kernel with the request list -- a stream that only has
+// hand-off misses / fired skipped hops gets its segments queued and is left PENDING (stat[s] = 2) instead of being flagged;
+// the queued segments are walked (fx_walk_kernel<..., EXT>, count read on the device); pass 2 stitches the pending streams
+// again, without a request list, and flags what is still not settled (FX_BLK_NEEDS_REPAIR: fxrx_collect takes over, as it
+// does for everything the fast path cannot do at all).  pass 0: the call of fxrx_collect's own repair rounds.
 extern "C" __global__ __launch_bounds__(CHAINFAST_THREADS)
 void fx_chainfast_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results, const FxFrame *frames, FxFrame *chain,
-                         uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair, FxWalkJob *jobs_rw, uint32_t *req_list)
+                         uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair, FxWalkJob *jobs_rw, uint32_t *req_list, uint32_t *stat, uint32_t pass)
 {
     __shared__ ChainLds C;
     const uint32_t s = blockIdx.x;
+    if (pass == 2u && stat[s] != 2u) return;                    // settled in pass 1, or beyond a repair round
     const FxStreamDesc sd = streams[s];
     FxStreamState st_in;
-    if (!chain_state_in(sd, s, st_in, chain_count, hdr)) return;
+    if (!chain_state_in(sd, s, st_in, chain_count, hdr)) { if (pass == 1u && threadIdx.x == 0) stat[s] = 3u; return; }
     uint32_t cnt = 0; int64_t fin_pos = 0, fin_floor = 0; bool fin_fresh = true;
     const unsigned long long t0_ = __builtin_readcyclecounter();
     if (threadIdx.x == 0) C.sh[5] = 0;
     __syncthreads();
     const bool ok = !force_repair && chain_fast_path<CHAINFAST_THREADS>(sd, jobs, results, frames, chain + sd.chain_base, C, cnt, fin_pos, fin_floor, fin_fresh,
-                                                                        jobs_rw, req_list, hdr);
+                                                                        pass == 2u ? nullptr : jobs_rw, pass == 2u ? nullptr : req_list, hdr);
     if (s == 0 && threadIdx.x == 0) { hdr->stamp[0] = (uint32_t)(__builtin_readcyclecounter() - t0_); }
     if (!ok) {
         if (threadIdx.x == 0) {
-            FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
-            *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
             // (FX_BLK_NEEDS_SLOW: not -- or not only -- hand-off misses: the full-size chain kernel has to go through it)
             const bool slow = force_repair || sd.n_jobs > CHAIN_MAXJ || C.sh[5];
-            atomicOr(&hdr->flags, (uint32_t)(FX_BLK_NEEDS_REPAIR | (slow ? FX_BLK_NEEDS_SLOW : 0)));
+            if (pass == 1u && !slow) stat[s] = 2u;               // its segments are queued: walked and stitched again within the chain
+            else {
+                FxStreamState so = st_in; so.invalid = 1; so.overflow = 0;
+                *sd.state_out = so; *sd.state_out_host = so; chain_count[s] = 0;
+                atomicOr(&hdr->flags, (uint32_t)(FX_BLK_NEEDS_REPAIR | (slow ? FX_BLK_NEEDS_SLOW : 0)));
+                if (pass) stat[s] = 3u;
+            }
         }
         return;
     }
+    if (pass && threadIdx.x == 0) stat[s] = 1u;
     chain_finish<CHAINFAST_THREADS>(sd, s, st_in, cnt, fin_pos, fin_floor, fin_fresh, chain_count, hdr);
     if (s == 0 && threadIdx.x == 0) hdr->stamp[3] = (uint32_t)(__builtin_readcyclecounter() - t0_);
 }
 
 extern "C" hipError_t fx_launch_chainfast(unsigned nstreams, hipStream_t st, const FxStreamDesc *streams, const FxWalkJob *jobs, const FxWalkResult *results,
                                           const FxFrame *frames, FxFrame *chain, uint32_t *chain_count, FxBlockHdr *hdr, uint32_t force_repair,
-                                          FxWalkJob *jobs_rw, uint32_t *req_list)
+                                          FxWalkJob *jobs_rw, uint32_t *req_list, uint32_t *stat, uint32_t pass)
 {
     hipLaunchKernelGGL(fx_chainfast_kernel, dim3(nstreams), dim3(CHAINFAST_THREADS), 0, st, streams, jobs, results, frames, chain, chain_count, hdr, force_repair,
-                       jobs_rw, req_list);
+                       jobs_rw, req_list, stat, pass);
     return hipGetLastError();
 }
 
@@ -1646,7 +1677,11 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
                      const FxTables *T)
 {
     constexpr int LEAD = EQ ? FX_EQ_TAPS - 1 : 0;
-    __shared__ float2 v[PMF_SPAN + LEAD + 4];
+    // the mixed-down span.  Without the equaliser it is kept de-interleaved -- even samples in ve[], odd ones in vo[] (v[m] =
+    // (m & 1 ? vo : ve)[m >> 1]) --: a symbol's taps alternate between the two, and neighbouring lanes, whose symbols sit two
+    // samples apart, then read neighbouring entries of each instead of every other one.
+    __shared__ float2 v[EQ ? PMF_SPAN + LEAD + 4 : 2];
+    __shared__ float2 ve[EQ ? 2 : (PMF_SPAN + 8) / 2 + 4], vo[EQ ? 2 : (PMF_SPAN + 8) / 2 + 4];
     __shared__ float2 u[EQ ? 2 * PMF_SYMS + FX_EQ_TAPS : 1];
     __shared__ float2 eqw[16];
     __shared__ float taps[FX_MF_TAPS];
@@ -1667,7 +1702,8 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
         if (EQ && tid < 16) eqw[tid] = tid < FX_EQ_TAPS ? chain[job.chain_idx].eq[tid] : make_float2(0.0f, 0.0f);
         for (int m = tid; m < span; m += PMF_THREADS) {
             const int64_t nn = nlo + m;                            // (nn >= 0: a payload symbol is hundreds of samples into the frame)
-            v[m] = derot(xld(xs, job.start + nn), job.mix_th + job.mix_dl * (uint32_t)nn, sc);
+            const float2 w = derot(xld(xs, job.start + nn), job.mix_th + job.mix_dl * (uint32_t)nn, sc);
+            if constexpr (EQ) v[m] = w; else (m & 1 ? vo : ve)[m >> 1] = w;
         }
         __syncthreads();
         if (EQ) {
@@ -1687,15 +1723,29 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
                 sym_raw[(size_t)job.sym_off + c0 + i] = eq_sum16(u + nc - (FX_EQ_TAPS - 1), eqw);
             }
         } else {
-            for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
-                const int nc = (int)(sym_sample(sym0 + c0 + i, job.mfc0) - nlo);
-                float ar = 0.0f, ai = 0.0f;
-#pragma unroll 7
-                for (int t = 0; t < FX_MF_TAPS; t++) {
-                    const float2 w = v[nc - t]; const float h = taps[t];
-                    ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
+            // two neighbouring symbols per thread (their 28-tap windows share 26 samples), one 16-byte store; each symbol's sum
+            // runs over its taps in ascending order, as everywhere.  (An odd last symbol computes a phantom neighbour into the
+            // padding of the frame's 8-symbol granule.)
+            static_assert(FX_MF_TAPS == 28, "tap loop below is written for 28 taps");
+            for (uint32_t j = tid; 2u * j < ns; j += PMF_THREADS) {
+                const uint32_t i0 = 2u * j;
+                const int nc0 = (int)(sym_sample(sym0 + c0 + i0, job.mfc0) - nlo);       // symbol i0 at span sample nc0, symbol i0 + 1 at nc0 + 2
+                const float2 *pa = (nc0 & 1) ? vo : ve, *pb = (nc0 & 1) ? ve : vo;       // samples of nc0's parity (even taps) / the other (odd taps)
+                const int ka = (nc0 >> 1) + 1, kb = ((nc0 - 1) >> 1) + 1;
+                float2 ea[15], ob[15];
+#pragma unroll
+                for (int k = 0; k < 15; k++) { ea[k] = pa[ka - k]; ob[k] = pb[kb - k]; }
+                float a0r = 0.0f, a0i = 0.0f, a1r = 0.0f, a1i = 0.0f;
+#pragma unroll
+                for (int h = 0; h < 14; h++) {
+                    const float h0 = taps[2 * h], h1 = taps[2 * h + 1];
+                    a0r = fmaf(h0, ea[h + 1].x, a0r); a0i = fmaf(h0, ea[h + 1].y, a0i);
+                    a0r = fmaf(h1, ob[h + 1].x, a0r); a0i = fmaf(h1, ob[h + 1].y, a0i);
+                    a1r = fmaf(h0, ea[h].x, a1r); a1i = fmaf(h0, ea[h].y, a1i);
+                    a1r = fmaf(h1, ob[h].x, a1r); a1i = fmaf(h1, ob[h].y, a1i);
                 }
-                sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
+                *reinterpret_cast<float4 *>(sym_raw + (size_t)job.sym_off + c0 + i0) =
+                    make_float4(a0r * job.mf_scale, a0i * job.mf_scale, a1r * job.mf_scale, a1i * job.mf_scale);
             }
         }
     }
@@ -2785,6 +2835,24 @@ __device__ __forceinline__ void vb2_step(const uint32_t (&Q)[64], uint32_t (&N)[
     da = ((unsigned long long)ah << 32) | al; db = ((unsigned long long)bh << 32) | bl;
 }
 
+// The traceback of the block BEFORE this one does not know its end state.  Survivors merge within a few constraint lengths, so
+// tracing this block's first FX_VB_TWARM steps back from state 0 arrives, almost always, at the state the true path passes
+// through at this block's first step: the guess.  It is made here, by the lane that has just written those decision words
+// (they come back from the L2, not from HBM -- fx_vbtrace_kernel used to read them a second time for this), and left in bits
+// 24..29 of the item's status word; fx_vbfinish_kernel verifies every guess against the state the traceback really arrives at.
+__device__ __forceinline__ void vb_trace16(const unsigned long long *dwl, uint32_t u0, uint32_t lim, unsigned &st, uint32_t &bits16);
+__device__ __forceinline__ uint32_t vb_make_guess(const unsigned long long *dwl, uint32_t len)
+{
+    const uint32_t wl = min((uint32_t)FX_VB_TWARM, len);
+    unsigned S = 0;
+    for (int grp = FX_VB_TWARM / 16 - 1; grp >= 0; grp--) {
+        if (16u * (uint32_t)grp >= wl) continue;
+        uint32_t unused = 0;
+        vb_trace16(dwl, 16u * (uint32_t)grp, wl, S, unused);
+    }
+    return (S & 63u) << 24;
+}
+
 // metric differences of one half to its smallest, as bytes (see vb_save_vec; the halves hold doubled metrics)
 __device__ __forceinline__ void vb2_save_vec(const uint32_t (&Q)[64], int half, uint8_t *dst)
 {
@@ -2896,9 +2964,9 @@ void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t it
     A.dwl = vb_slab(dwv, slot_a, blk); A.vec = vec_arena + (size_t)slot_a * 128u;
     B.enc = bufB + jb.byte_off; B.on = ib.on; B.first = !ib.on || ib.b == 0; B.t_reg = B.first && !ib.on ? 0u : ib.t_reg; B.t1 = ib.t1;
     B.dwl = vb_slab(dwv, ib.on ? slot_b : slot_a, blk); B.vec = vec_arena + (size_t)(ib.on ? slot_b : slot_a) * 128u;
-    if (ia.on) vb_st[slot_a] = 0u;
-    if (ib.on) vb_st[slot_b] = 0u;
     vb2_forward(p, blk, A, B);
+    if (ia.on) vb_st[slot_a] = vb_make_guess(A.dwl, ia.t1 - ia.t_reg);
+    if (ib.on) vb_st[slot_b] = vb_make_guess(B.dwl, ib.t1 - ib.t_reg);
 }
 
 // The same pass, one work item per lane (32-bit metrics): twice the waves of the packed kernel at about 1.6 x its instructions
@@ -2919,9 +2987,9 @@ void fx_vbfwd1_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t i
     const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)live) - 1, 64));
     uint8_t *vec = vec_arena + (size_t)slot * 128u;
     const bool first = !it.on || it.b == 0;
-    if (it.on) vb_st[slot] = 0u;
     vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, first ? 1 : 0, nullptr, vb_slab(dwv, slot, blk), first ? nullptr : vec, vec + 64,
                vb_warm(p) + blk, vb_warm(p), it.on);
+    if (it.on) vb_st[slot] = vb_make_guess(vb_slab(dwv, slot, blk), it.t1 - it.t_reg);
 }
 
 __device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
@@ -2954,7 +3022,7 @@ void fx_vbfix_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t it
     const FxPayJob &job = jobs[it.g];
     const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)fails) - 1, 64));
     vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, 2, bad ? vec - 64 : vec, vb_slab(dwv, slot, blk), vec, vec + 64, blk, 0u, bad);
-    if (bad) vb_st[slot] = VB_ST_REP;                                       // (fx_vbfinish_kernel counts these)
+    if (bad) vb_st[slot] = VB_ST_REP | vb_make_guess(vb_slab(dwv, slot, blk), it.t1 - it.t_reg);   // (fx_vbfinish_kernel counts these; the guess: from the new decisions)
 }
 
 // sixteen traceback steps u0 + 15 .. u0 of one lane (those below lim only): the words first, then the chain through them
@@ -3015,17 +3083,12 @@ void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t 
     uint32_t flags = it.on ? (vb_st[slot] & VB_ST_REP) : 0u;
     const uint8_t *vec = vec_arena + (size_t)slot * 128u;
     if (it.on && it.b > 0 && !vb_same64(vec, vec - 64)) flags |= VB_ST_BAD;
-    // the end state: 0 behind the flushed tail, a guess elsewhere
+    // the end state: 0 behind the flushed tail; elsewhere the guess the next block's forward pass left (its first FX_VB_TWARM
+    // steps traced back from state 0)
     const bool has_next = it.on && it.b + 1u < it.nblk;
-    // (dbg bit 0, tests only: no warm-up, the guess is state 0 -- wrong 63 times in 64, for the re-trace path to be exercised)
-    const uint32_t wl = has_next && !(dbg & 1u) ? min((uint32_t)FX_VB_TWARM, min(blk, it.Tn - (it.t_reg + blk))) : 0u;
-    const unsigned long long *dwn = vb_slab(dwv, has_next ? slot + 1u : slot, blk);
-    unsigned S = 0;
-    for (int grp = FX_VB_TWARM / 16 - 1; grp >= 0; grp--) {
-        if (!__any(16u * (uint32_t)grp < wl)) continue;
-        uint32_t unused = 0;
-        vb_trace16(dwn, 16u * (uint32_t)grp, wl, S, unused);
-    }
+    // (dbg bit 0, tests only: the guess is state 0 -- wrong 63 times in 64, for the re-trace path to be exercised)
+    const uint32_t old = it.on ? vb_st[slot] : 0u;
+    const unsigned S = (has_next && !(dbg & 1u)) ? ((vb_st[slot + 1u] >> 24) & 63u) : 0u;
     const unsigned long long *dwl = vb_slab(dwv, slot, blk);
     uint8_t *A = bufA + job.byte_off + it.t_reg / 8u;
     unsigned st = S;
@@ -3035,7 +3098,7 @@ void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t 
         st = vb_trace_chunk(dwl, (uint32_t)c, len, st, b0, b1);
         if (64u * (uint32_t)c < len) vb_emit(A, (uint32_t)c, b0, b1);
     }
-    if (it.on) vb_st[slot] = S | (st << 8) | flags;
+    if (it.on) vb_st[slot] = S | (st << 8) | flags | (old & 0x3F000000u);       // (the guess bits stay: the item before this one may still be reading them)
 }
 
 // One block's traceback again, by a whole wave (its end-state guess was wrong): parallel over 64-step chunks with exact

@@ -120,10 +120,13 @@ static int h84_ready = 0;
 static void h84_init(void)
 {
     if (h84_ready) return;
+    /* [RECALLED -- confident] liquid's fec_hamming84.c generator table: bits [p1 p2 d1 p4 d2 d3 d4 p8], MSB first, d1 the
+     * nibble's MSB; p1 = d1^d2^d4, p2 = d1^d3^d4, p4 = d2^d3^d4, p8 = overall (even) parity.  The table below is that rule
+     * evaluated, and equals the sixteen literals as recalled (00 d2 55 87 99 4b cc 1e e1 33 b4 66 78 aa 2d ff). */
     for (unsigned d = 0; d < 16; d++) {
-        unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
-        unsigned p0 = d0 ^ d1 ^ d3, p1 = d0 ^ d2 ^ d3, p2 = d1 ^ d2 ^ d3;
-        unsigned c = (d << 4) | (p2 << 3) | (p1 << 2) | (p0 << 1);
+        unsigned d1 = (d >> 3) & 1, d2 = (d >> 2) & 1, d3 = (d >> 1) & 1, d4 = d & 1;
+        unsigned p1 = d1 ^ d2 ^ d4, p2 = d1 ^ d3 ^ d4, p4 = d2 ^ d3 ^ d4;
+        unsigned c = (p1 << 7) | (p2 << 6) | (d1 << 5) | (p4 << 4) | (d2 << 3) | (d3 << 2) | (d4 << 1);
         c |= (unsigned)__builtin_popcount(c) & 1u;
         h84_enc[d] = (uint8_t)c;
     }
@@ -218,9 +221,9 @@ static unsigned gol_syndrome(uint32_t cw)                 /* parity part recompu
 static void blk_init(void)
 {
     if (blk_ready) return;
-    for (unsigned d = 0; d < 16; d++) {                    /* systematic (7,4): d3 d2 d1 d0 p2 p1 p0 */
-        unsigned d0 = d & 1, d1 = (d >> 1) & 1, d2 = (d >> 2) & 1, d3 = (d >> 3) & 1;
-        h74_enc[d] = (uint8_t)((d << 3) | ((d1 ^ d2 ^ d3) << 2) | ((d0 ^ d2 ^ d3) << 1) | (d0 ^ d1 ^ d3));
+    for (unsigned d = 0; d < 16; d++) {                    /* [RECALLED -- confident] liquid's fec_hamming74.c table: [p1 p2 d1 p4 d2 d3 d4] (00 69 2a 43 4c 25 66 0f 70 19 5a 33 3c 55 16 7f) */
+        unsigned d1 = (d >> 3) & 1, d2 = (d >> 2) & 1, d3 = (d >> 1) & 1, d4 = d & 1;
+        h74_enc[d] = (uint8_t)(((d1 ^ d2 ^ d4) << 6) | ((d1 ^ d3 ^ d4) << 5) | (d1 << 4) | ((d2 ^ d3 ^ d4) << 3) | (d2 << 2) | (d3 << 1) | d4);
     }
     for (unsigned r = 0; r < 128; r++) { unsigned best = 0, bd = 99; for (unsigned d = 0; d < 16; d++) { unsigned w = (unsigned)__builtin_popcount(r ^ h74_enc[d]); if (w < bd) { bd = w; best = d; } } h74_dec[r] = (uint8_t)best; }
     for (unsigned d = 0; d < 256; d++) {                   /* (12,8): data bits at positions 3,5,6,7,9,10,11,12 (1-based), parity at 1,2,4,8 */

@@ -170,6 +170,7 @@ int main(int argc, char **argv)
     }
     std::normal_distribution<float> nd(0.0f, 0.04f);
     for (size_t n = 0; n < x.size(); n++) x[n] = x[n] * std::polar(1.0f, -0.015f * (float)n + 0.2f) + gr_complex(nd(rng), nd(rng));
+    x.insert(x.end(), 70000, gr_complex(0, 0));                               // the per-sample detector drop-in searches 64 Ki-sample blocks: push the last one through
     while (x.size() % 256) x.push_back(gr_complex(0, 0));
 
     rx_calls rx;

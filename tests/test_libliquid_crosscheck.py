@@ -2,7 +2,10 @@
 libliquid cross-check compiled only if a system liquid.h is found").  The build image has none, so here this test SKIPS and
 parity with liquid-dsp stays unpinned.  Where it does run: frames made by this repo's host generator go
 through liquid's own flexframesync in 256-sample calls and must come out with the payload bytes that went in; a failure
-there is exactly the information the "parity unpinned" note says is missing."""
+there is exactly the information the "parity unpinned" note says is missing.  And the direction that matters for a drop-in
+RECEIVER: frames made by liquid's own flexframegen (with the reference's flex_tx properties) go through this repo's oracle
+and -- when a GPU is there -- through libfxrx.so; INTEGRATION.md section 1b lists which on-air elements are restated from
+recollection and would be the first suspects if this ever fails."""
 import os, shutil, subprocess
 import numpy as np
 import pytest
@@ -10,7 +13,7 @@ import pytest
 HEADERS = ["/usr/include/liquid/liquid.h", "/usr/local/include/liquid/liquid.h", "/opt/liquid/include/liquid/liquid.h"]
 
 
-def test_frames_of_this_generator_through_a_real_flexframesync(tmp_path):
+def _build(tmp_path):
     hdr = next((h for h in HEADERS if os.path.exists(h)), None)
     if hdr is None or shutil.which("gcc") is None:
         pytest.skip("no system liquid-dsp (looked for %s): parity with liquid-dsp stays unpinned" % ", ".join(HEADERS))
@@ -21,6 +24,38 @@ def test_frames_of_this_generator_through_a_real_flexframesync(tmp_path):
                         capture_output=True, text=True)
     if cc.returncode != 0:
         pytest.skip("liquid.h found at %s but the cross-check does not build against it:\n%s" % (hdr, cc.stderr[-2000:]))
+    return exe
+
+
+def test_frames_of_a_real_flexframegen_through_this_receiver(tmp_path):
+    """liquid TX -> own RX (oracle always; libfxrx.so too when a HIP device is present)."""
+    exe = _build(tmp_path)
+    import importlib
+    import oracle_ffi as oracle
+    from parity_util import oracle_frames
+    iq = tmp_path / "liquid_frames.c64"
+    seed = 12345
+    out = subprocess.run([str(exe), "tx", str(iq), str(seed)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    want = []
+    for n in (1024, 64, 300):
+        pl = bytearray()
+        for _ in range(n):
+            seed = (seed * 1103515245 + 12345) & 0xFFFFFFFF
+            pl.append((seed >> 16) & 0xFF)
+        want.append(bytes(pl))
+    x = np.fromfile(iq, dtype=np.complex64)
+    x = np.concatenate([x, np.zeros((-len(x)) % 256 + 1024, np.complex64)])
+    of = oracle_frames(oracle, x)
+    assert [(f.header_valid, f.payload_valid, f.payload) for f in of] == [(1, 1, pl) for pl in want], "the oracle does not receive liquid's frames: wire format differs"
+    fx = importlib.import_module("gr-liquiddsp_amd")
+    if fx.lib().fxrx_device_count() > 0:
+        got = fx.RxContext(1).process([x])
+        assert [(g["header_valid"], g["payload_valid"], g["payload"]) for g in got] == [(1, 1, pl) for pl in want]
+
+
+def test_frames_of_this_generator_through_a_real_flexframesync(tmp_path):
+    exe = _build(tmp_path)
     import oracle_ffi as oracle
     rng = np.random.default_rng(7)
     payloads = [bytes(rng.integers(0, 256, n, dtype=np.uint8)) for n in (1024, 64, 300)]

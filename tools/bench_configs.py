@@ -99,7 +99,11 @@ def run_rank(a, key, rank, world, dist, rdev, stub):
         ctx.reset(); res = ctx.results(ctx.process_raw(ptrs[gi], counts, True))
         a_, b_, c_ = check_group(fx, res, inj, cfg["detect"], len(inj)); n_inj += a_; n_found += b_; n_ok += c_; n_frames += len(res)
     out.update(frames=n_frames, injected=n_inj, found=n_found, payload_ok=n_ok)
-    if n_found != n_inj and not a.allow_missing:
+    # (a sequential synchroniser does not find every injected frame: a false alarm on a frame's tail costs it 618 samples and a
+    # preamble inside them is gone, and at 20 dB a header fails now and then -- a few in a hundred thousand, in the oracle as
+    # here: tests/test_gpu_configs.py compares such streams with it; more than that is an error)
+    out["not_found"] = n_inj - n_found
+    if n_inj - n_found > max(2, n_inj // 5000) and not a.allow_missing:
         raise SystemExit("bench_configs: found %d of %d injected frames -- refusing to report a throughput" % (n_found, n_inj))
 
     def sync():
