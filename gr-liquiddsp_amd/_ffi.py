@@ -84,7 +84,7 @@ EXPORTS = [
     "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
     "fxrx_outer_from_index", "fxrx_outer_to_index",
     "fxtx_create", "fxtx_destroy", "fxtx_frame_len", "fxtx_generate",
-    "fxtx_apply_channel", "fxrx_ready", "fxrx_inflight", "fxrx_debug_fail", "fxrx_pinned_alloc", "fxrx_pinned_free", "fxrx_sync_context",
+    "fxtx_apply_channel", "fxrx_set_timing", "fxrx_debug_block_times", "fxrx_ready", "fxrx_inflight", "fxrx_debug_fail", "fxrx_pinned_alloc", "fxrx_pinned_free", "fxrx_sync_context",
 ]
 
 
@@ -164,6 +164,8 @@ def lib():
     L.fxrx_submit.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_int]
     L.fxrx_collect.restype = C.c_int; L.fxrx_collect.argtypes = [C.c_void_p]
     L.fxrx_set_depth.restype = C.c_int; L.fxrx_set_depth.argtypes = [C.c_void_p, C.c_uint]
+    L.fxrx_set_timing.restype = C.c_int; L.fxrx_set_timing.argtypes = [C.c_void_p, C.c_int]
+    L.fxrx_debug_block_times.restype = C.c_int; L.fxrx_debug_block_times.argtypes = [C.c_void_p, C.POINTER(C.c_double * 4)]
     L.fxrx_ready.restype = C.c_int; L.fxrx_ready.argtypes = [C.c_void_p]
     L.fxrx_inflight.restype = C.c_uint; L.fxrx_inflight.argtypes = [C.c_void_p]
     L.fxrx_debug_fail.restype = C.c_int; L.fxrx_debug_fail.argtypes = [C.c_void_p, C.c_uint, C.c_uint]

@@ -107,19 +107,19 @@ int dropin_feed_raw(const float *iq, unsigned long long n_samples, unsigned repe
 double dropin_copy_ceiling(const float *iq, unsigned long long n_samples, unsigned block, unsigned repeats)
 {
     using clk = std::chrono::steady_clock;
-    fx_complex *buf = (fx_complex *)fxrx_pinned_alloc((size_t)block * sizeof(fx_complex));
-    if (!buf) return 0.0;
+    fx_complex *buf[4];                                         // a ring like the library's: the destination is never cache-resident
+    for (auto &b : buf) { b = (fx_complex *)fxrx_pinned_alloc((size_t)block * sizeof(fx_complex)); if (!b) return 0.0; }
     volatile size_t sink = 0;
     const auto t0 = clk::now();
     for (unsigned r = 0; r < (repeats ? repeats : 1u); r++) {
-        size_t fill = 0;
+        size_t fill = 0; unsigned cur = 0;
         for (unsigned long long p = 0; p + 256 <= n_samples; p += 256) {
-            std::memcpy(buf + fill, iq + 2 * p, 256 * sizeof(fx_complex));
-            fill += 256; if (fill + 256 > block) { sink = sink + fill; fill = 0; }
+            std::memcpy(buf[cur] + fill, iq + 2 * p, 256 * sizeof(fx_complex));
+            fill += 256; if (fill + 256 > block) { sink = sink + fill; fill = 0; cur = (cur + 1) & 3u; }
         }
     }
     const double dt = std::chrono::duration<double>(clk::now() - t0).count();
-    fxrx_pinned_free(buf);
+    for (auto b : buf) fxrx_pinned_free(b);
     return (double)(repeats ? repeats : 1u) * (double)(n_samples - n_samples % 256) / dt;
 }
 #endif

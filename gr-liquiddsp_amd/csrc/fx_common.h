@@ -44,7 +44,7 @@
 #define FX_FLEX_WAVES 4
 #endif
 #ifndef FX_DETECT_WAVES
-#define FX_DETECT_WAVES 8
+#define FX_DETECT_WAVES 4
 #endif
 #ifndef FX_VERIFY_WAVES
 #define FX_VERIFY_WAVES 4
@@ -194,7 +194,7 @@ struct FxBlockHdr {                      // device memory, zeroed at submit; mir
     uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
     uint64_t sym_total, byte_total, dw_total, out_total;
     uint32_t hops, hops_cheap, repairs, verify_hops, verify_failures, walk_jobs_run;
-    uint32_t stream_frames0;             // (scratch)
+    uint32_t vb_ticket;                  // fx_vbfinish_kernel: waves done (the last one publishes n_vb_fallback to the host's copy)
     uint32_t done;                       // host mirror only: written last
     uint32_t stamp[8];
 };

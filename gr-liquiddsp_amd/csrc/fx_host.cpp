@@ -66,8 +66,8 @@ extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hip
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
                                         const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed);
 extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
-                                         uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
-                                         uint8_t *out, FxOutRec *recs);
+                                         uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint8_t *vec_arena, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
+                                         uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_host);
 extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                       const FxFrame *chain, float2 *sym_raw, const FxTables *T);
 extern "C" hipError_t fx_launch_paypll(unsigned grid_waves, unsigned waves_per_wg, hipStream_t st, const FxPayJob *jobs, const uint32_t *pll_list, const FxBlockHdr *hdr,
@@ -121,7 +121,7 @@ template <class T> struct PinBuf {
     ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
 
-constexpr unsigned kMaxDepth = 16;
+constexpr unsigned kMaxDepth = 32;
 constexpr unsigned kStateRing = kMaxDepth + 3;      // FxStreamState records per stream: one per block in flight and then some
 constexpr uint32_t kFallbackWaves = 32;             // in-chain launch for frames the batch Viterbi path hands back (normally none)
 constexpr uint32_t kRepairCap = 256;                // frame-table slots per stream for walks done by the chain kernel
@@ -181,7 +181,10 @@ struct Slot {
     double host_submit_ms = 0.0;
     bool any_late = false;
     uint32_t dec_launched = 0, rs_launched = 0;   // decode waves launched with the chain (lean / Reed-Solomon instance)
+    double dbg_submit_ms = 0.0, dbg_collect_ms = 0.0, dbg_gpu_start_ms = 0.0, dbg_gpu_done_ms = 0.0;   // fxrx_debug_block_times
     bool force_noskip = false;               // walk this block with the exact detector on every hop (nothing to verify)
+    int timing_level = 0;                    // which stage events this block recorded (fxrx_set_timing)
+    bool inchain = false;                    // the repair round within the chain was enqueued with it
     uint32_t kept_hops = 0, kept_cheap = 0, kept_vhops = 0, kept_vfail = 0, kept_repairs = 0;   // walk-phase counters of a block whose back part was run again
 };
 
@@ -202,7 +205,14 @@ struct fxrx_ctx_s {
     uint64_t plain_hint = 0, batch_hint = 0, vb_items_hint = 0, vb_steps_hint = 0, vb_want_hint = 0;   // likewise: frames of the wave-per-frame / batch decoders, trellis blocks, trellis steps
     bool first_block = true;             // nothing collected yet: grids cover their lists' capacity
     bool batch_viterbi = true;           // FXRX_BATCH_VITERBI=0: every frame through the wave-per-frame decoder
-    bool inchain_repair = true;          // FXRX_INCHAIN_REPAIR=0: no repair round within the chain (everything that takes a walk waits for fxrx_collect)
+    // The repair round within the chain costs two launches per block -- and launches are what the pipeline is short of (DESIGN.md
+    // section 6) --, so it is only enqueued while blocks keep needing it: for the next 16 blocks after one that did.
+    // FXRX_INCHAIN_REPAIR=0: never, 1: while needed (default), 2: always.
+    int inchain_repair = 1; unsigned inchain_left = 0;
+    int timing_level = -1;               // stage events per block: -1 auto (all stages one block at a time, none with blocks in flight) | 0 none | 1 the PLL only | 2 all stages
+    hipEvent_t ref_event = nullptr; double ref_host_ms = 0.0;   // fxrx_debug_block_times: a common origin of GPU and host clocks
+    int debug_stop_after = 0;            // FXRX_DEBUG_STOP_AFTER (tools/dev/dev_stage_cost.py): 4 plan | 5 matched filter | 6 PLL -- the chain ends there, no results
+    uint64_t fb_hint = 0;                // frames the last collected block's batch Viterbi path handed back (sizes the fallback launch; 0: none enqueued)
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
     hipStream_t st_chain = nullptr;      // highest priority: the state-dependent stretch of continuing blocks (true walkers, their verification, chain kernel)
     uint32_t verify_per_cu = 4;          // FXRX_VERIFY_PER_CU: workgroups of the seek verifier per CU (they stride over the runs)
@@ -351,7 +361,9 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
-    if (const char *e = std::getenv("FXRX_INCHAIN_REPAIR")) c->inchain_repair = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_INCHAIN_REPAIR")) c->inchain_repair = std::min(2, std::max(0, std::atoi(e)));
+    if (const char *e = std::getenv("FXRX_DEBUG_STOP_AFTER")) c->debug_stop_after = std::atoi(e);
+    if (const char *e = std::getenv("FXRX_TIMING")) c->timing_level = std::min(2, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VERIFY_PER_CU")) c->verify_per_cu = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_MF_PER_CU")) c->mf_per_cu = (uint32_t)std::min(64, std::max(0, std::atoi(e)));
@@ -392,6 +404,23 @@ int fxrx_set_depth(fxrx_ctx *c, unsigned int depth)
     HIP_OK(hipSetDevice(c->cfg.device));
     while (c->slots.size() < depth + 1) if (make_slot(c) != 0) return FXRX_ERR_HIP;
     c->depth = depth; c->head = c->tail = 0; c->last = nullptr;
+    return 0;
+}
+
+// diagnostics (timing level 2 set before the first submit): of the last collected block, in ms since a common origin --
+// host time when fxrx_submit was entered, GPU time of its first stage event, GPU time of its last event, host time when
+// fxrx_collect had it
+int fxrx_debug_block_times(const fxrx_ctx *c, double out[4])
+{
+    if (!c || !c->last || !out) return FXRX_ERR_ARG;
+    out[0] = c->last->dbg_submit_ms; out[1] = c->last->dbg_gpu_start_ms; out[2] = c->last->dbg_gpu_done_ms; out[3] = c->last->dbg_collect_ms;
+    return 0;
+}
+
+int fxrx_set_timing(fxrx_ctx *c, int level)
+{
+    if (!c || level < -1 || level > 2) return FXRX_ERR_ARG;
+    c->timing_level = level;
     return 0;
 }
 
@@ -547,7 +576,9 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
 
     // ---- 3. the chain, front part: walkers and seek verification ----
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
-    HIP_OK(hipEventRecord(sl.ev[0], st));
+    const int tl = c->timing_level >= 0 ? c->timing_level : (c->depth > 1 ? 0 : 2);      // stage events: see fxrx_set_timing
+    sl.timing_level = tl;
+    if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[0], st));
     HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ, nullptr, 0u));
     // the true walkers of continuing streams read the state the previous block's chain kernel leaves.  What the speculative
     // walkers skipped is verified before that wait -- it does not depend on the state --, so that the chain of dependencies
@@ -573,11 +604,11 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         if (c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
         HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)late.size(), cst, d_jobs, d_list + early.size(), sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ, nullptr, 0u));
     }
-    HIP_OK(hipEventRecord(sl.ev[1], cst));
+    if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[1], cst));
     if (verify)
         HIP_OK(fx_launch_seekverify(late.empty() ? c->verify_per_cu * (unsigned)c->n_cus : (unsigned)std::min<size_t>((size_t)c->verify_per_cu * (size_t)c->n_cus, std::max<size_t>(64, 16 * late.size())), cst, sl.d_runs.p,
                                     sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 1u));
-    HIP_OK(hipEventRecord(sl.ev[2], cst));
+    if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[2], cst));
     // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
     // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
     if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
@@ -609,7 +640,9 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
         hipStream_t cs = chain_st ? chain_st : st;
         FxWalkJob *d_jobs_rw = reinterpret_cast<FxWalkJob *>(sl.d_desc.p);
         const uint32_t req_cap = (uint32_t)(2 * sl.NJ + 16);
-        if (c->chain_slow || !c->inchain_repair)
+        sl.inchain = !c->chain_slow && (c->inchain_repair == 2 || (c->inchain_repair == 1 && c->inchain_left > 0));
+        if (c->inchain_left) c->inchain_left--;
+        if (!sl.inchain)
             HIP_OK(fx_launch_chainfast(NS, cs, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, c->chain_slow ? 1u : 0u, nullptr, nullptr, nullptr, 0u));
         else {
             HIP_OK(fx_launch_chainfast(NS, cs, d_streams, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_chain.p, sl.d_chain_count.p, hdr, 0u, d_jobs_rw, sl.d_req.p, sl.d_cstat.p, 1u));
@@ -626,7 +659,9 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
     HIP_OK(fx_launch_plan(st, c->plan_grid ? c->plan_grid : (unsigned)std::min<uint64_t>(64, c->frames_hint / 2048 + 1), d_streams, NS, detect ? 1u : 0u, c->cfg.equalizer ? 1u : 0u, sl.vb_blk, sl.d_chain.p,
                           sl.d_chain_count.p, sl.d_stream_base.p, sl.d_pjobs.p, sl.h_recs.p, sl.d_mf_job.p, sl.d_mf_c0.p, sl.mf_cap, sl.d_pll_list.p, sl.d_dec_list.p, list_cap,
                           sl.d_vb_items.p, sl.vb_cap, hdr, hdr_pay, sl.h_hdr.p, sl.d_plan_ws.p));
-    HIP_OK(hipEventRecord(sl.ev[4], st));
+    const int tl = sl.timing_level;
+    if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[4], st));
+    if (c->debug_stop_after == 4) { c->carry_reader[b % 3] = nullptr; HIP_OK(hipEventRecord(sl.ev[8], st)); return 0; }
     if (!detect) {
         // grids stride over lists whose lengths only the device knows; size them from what the last block held
         const uint64_t fh = c->frames_hint ? std::min<uint64_t>(chain_slots, c->frames_hint + c->frames_hint / 2 + 64) : chain_slots;
@@ -637,9 +672,11 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
         HIP_OK(fx_launch_paymf(mf_grid, c->cfg.equalizer ? 1 : 0, st, sl.d_pjobs.p, sl.d_mf_job.p, sl.d_mf_c0.p, hdr_pay, sl.d_chain.p, sl.d_symraw.p, c->d_tables));
         HIP_OK(hipEventRecord(sl.ev[5], st));
         c->carry_reader[b % 3] = sl.ev[5];
+        if (c->debug_stop_after == 5) { HIP_OK(hipEventRecord(sl.ev[8], st)); return 0; }
         HIP_OK(fx_launch_paypll((unsigned)(fh / 64 + FX_PLL_CLASSES), c->pll_waves, st, sl.d_pjobs.p, sl.d_pll_list.p, hdr_pay, sl.d_symraw.p, sl.d_symraw.p,
                                 sl.d_hard.p, sl.h_recs.p, c->d_tables));
-        HIP_OK(hipEventRecord(sl.ev[6], st));
+        if (tl >= 1) HIP_OK(hipEventRecord(sl.ev[6], st));
+        if (c->debug_stop_after == 6) { HIP_OK(hipEventRecord(sl.ev[8], st)); return 0; }
         FxPayResult *pres = nullptr;
 #ifdef FX_STAMPS
         pres = sl.d_pres.p;
@@ -658,7 +695,8 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
         // still has to be given its registers before it can leave: so the grid covers what the last block held plus a margin,
         // not the list's capacity, and the Reed-Solomon instance (256 registers a wave) is only launched while such frames
         // keep turning up.  What a launch did not cover is decoded when the block is collected (finish_decode).
-        sl.dec_launched = c->first_block ? chain_slots : (unsigned)std::min<uint64_t>(chain_slots, c->plain_hint + c->plain_hint / 2 + 64);
+        // (the plain instance too is only launched while such frames keep turning up: with the batch path on, a block normally has none)
+        sl.dec_launched = c->first_block ? chain_slots : (c->plain_hint || !sl.vb_blk ? (unsigned)std::min<uint64_t>(chain_slots, c->plain_hint + c->plain_hint / 2 + 64) : 0u);
         sl.rs_launched = c->rs_hint ? (unsigned)std::min<uint64_t>(chain_slots, c->rs_hint + c->rs_hint / 2 + 64) : 0u;
         HIP_OK(fx_launch_paydec(0, soft, 0, sl.dec_launched, c->dec_waves, st, sl.d_pjobs.p, sl.d_dec_list.p, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, sl.d_soft.p,
                                 sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, nullptr));
@@ -674,18 +712,22 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
             HIP_OK(fx_launch_vbitems(0, sl.vb_items_launched, st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p,
                                      sl.d_vb_st.p, c->vb_debug, vb_packed));
             HIP_OK(fx_launch_vbfinish(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
-                                      sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p));
-            // frames whose hand-overs could not be verified (a repair behind a repair): the wave-per-frame decoder, a few waves
-            sl.fb_launched = kFallbackWaves;
+                                      sl.d_vb_vec.p, sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p, sl.h_hdr.p));
+            // frames whose hand-overs could not be verified (a block that ran again and ended differently): the wave-per-frame decoder,
+            // launched with the chain only while such frames keep turning up (the count reaches the host either way; what a launch
+            // did not cover is decoded when the block is collected)
+            sl.fb_launched = (c->first_block || c->fb_hint || c->vb_debug) ? (uint32_t)std::min<uint64_t>(chain_slots, std::max<uint64_t>(kFallbackWaves, c->fb_hint + c->fb_hint / 2 + 16)) : 0u;
             HIP_OK(fx_launch_paydec(0, 0, 0, sl.fb_launched, 1u, st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
                                     sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
         } else sl.vb_pre_launched = sl.vb_items_launched = sl.fb_launched = 0;
-        HIP_OK(hipEventRecord(sl.ev[7], st));
+        if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[7], st));
         // (a copy kernel: it knows how many symbols the block really holds)
         if (c->cfg.want_framesyms)
             HIP_OK(fx_launch_symcopy(2u * (unsigned)c->n_cus, st, hdr_pay, sl.d_symraw.p, sl.h_framesyms.p));
     } else {
-        HIP_OK(hipEventRecord(sl.ev[5], st)); HIP_OK(hipEventRecord(sl.ev[6], st)); HIP_OK(hipEventRecord(sl.ev[7], st));
+        HIP_OK(hipEventRecord(sl.ev[5], st));
+        if (tl >= 1) HIP_OK(hipEventRecord(sl.ev[6], st));
+        if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[7], st));
         c->carry_reader[b % 3] = sl.ev[5];
     }
     HIP_OK(hipEventRecord(sl.ev[8], st));
@@ -729,6 +771,10 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         S.total += (int64_t)nn; S.fresh_start = false;
         S.carry_bound = std::min<int64_t>(S.carry_cap, sl.snap[s].carry_bound + (int64_t)nn);
     }
+    if (c->timing_level >= 2 && !c->ref_event) {
+        if (hipEventCreate(&c->ref_event) == hipSuccess) { (void)hipEventRecord(c->ref_event, sl.st); (void)hipEventSynchronize(c->ref_event); c->ref_host_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    }
+    sl.dbg_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->ref_host_ms;
     sl.timing.samples = total_new;
     if (c->debug_fail_submit) { c->debug_fail_submit--; set_err("fxrx_submit: injected failure (fxrx_debug_fail)"); return FXRX_ERR_STATE; }
     int r = enqueue_block(c, sl);
@@ -814,7 +860,7 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
         const uint32_t flags = sl.h_hdr.p->flags;
         if (std::getenv("FXRX_DEBUG_ROUNDS")) std::fprintf(stderr, "[fxrx] block %llu at collect: flags %x verify_failures %u (pass %d)\n", (unsigned long long)sl.seq, flags, sl.h_hdr.p->verify_failures, round);
         if (flags & FX_BLK_NEEDS_REPAIR) {
-            c->repairs_host++;
+            c->repairs_host++; c->inchain_left = 16;
             const FxBlockHdr &h0 = *sl.h_hdr.p;         // the walk-phase counters are zeroed with the first plan kernel: keep them
             sl.kept_hops += h0.hops; sl.kept_cheap += h0.hops_cheap; sl.kept_vhops += h0.verify_hops; sl.kept_vfail += h0.verify_failures;
             if (!sl.force_noskip && c->cfg.mode != FXRX_MODE_DETECTOR && c->skip_seek && h0.verify_failures > std::max<uint32_t>(16u, (uint32_t)sl.NJ / 8u)) {
@@ -901,8 +947,9 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
         HIP_OK(hipMemsetAsync(&hdr_pay->n_vb_fallback, 0, sizeof(uint32_t), sl.st));
         HIP_OK(fx_launch_vbpre(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
         HIP_OK(fx_launch_vbitems(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p, sl.d_vb_st.p, c->vb_debug, 1));
+        HIP_OK(hipMemsetAsync(&hdr_pay->vb_ticket, 0, sizeof(uint32_t), sl.st));
         HIP_OK(fx_launch_vbfinish(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
-                                  sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p));
+                                  sl.d_vb_vec.p, sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p, sl.h_hdr.p));
         HIP_OK(fx_launch_paydec(0, 0, 0, kFallbackWaves, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
                                 sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
         sl.vb_pre_launched = h.n_dec_batch; sl.vb_items_launched = h.n_vb_items; sl.fb_launched = kFallbackWaves;
@@ -989,7 +1036,11 @@ static int collect_block(fxrx_ctx_s *c)
         if (flags & FX_BLK_INVALID) { set_err("fxrx_collect: block has no valid start state"); return FXRX_ERR_STATE; }
         if (flags & (FX_BLK_CARRY_OVERFLOW | FX_BLK_NEEDS_REPAIR)) { int r = repair_and_replay(c, sl); if (r) return r; }
     }
+    sl.dbg_collect_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->ref_host_ms;
+    if (sl.timing_level >= 2 && c->ref_event) { float m = 0; (void)hipEventElapsedTime(&m, c->ref_event, sl.ev[0]); sl.dbg_gpu_start_ms = m; (void)hipEventElapsedTime(&m, c->ref_event, sl.ev[8]); sl.dbg_gpu_done_ms = m; }
+    if (c->debug_stop_after) { sl.out.clear(); sl.busy = false; c->last = &sl; c->tail = (c->tail + 1) % nslots; c->inflight--; return 0; }
     if (c->cfg.mode != FXRX_MODE_DETECTOR) { int r = finish_decode(c, sl); if (r) return r; }
+    if (sl.h_hdr.p->n_repair_req) c->inchain_left = 16;
     if (sl.h_hdr.p->n_repair_req && sl.h_hdr.p->verify_failures) {
         // the chain mended something by itself: streams in which a skipped hop fired are walked with the exact detector on every
         // hop for their next blocks (the list says which; a rare, small copy)
@@ -1035,19 +1086,21 @@ static int collect_block(fxrx_ctx_s *c)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
     c->frames_hint = h.n_frames; c->plain_hint = h.n_dec_plain; c->batch_hint = h.n_dec_batch; c->vb_items_hint = h.n_vb_items;
-    c->mf_items_hint = h.n_mfblk; c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
+    c->fb_hint = h.n_vb_fallback; c->mf_items_hint = h.n_mfblk; c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
     c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - std::min<uint64_t>(c->rs_hint, std::max<uint64_t>(1, c->rs_hint / 8));   // (fades out, to zero, over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;
     float ms = 0;
-    (void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]); t.walk_ms = ms;
-    (void)hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]); t.seekverify_ms = ms;
-    (void)hipEventElapsedTime(&ms, sl.ev[2], sl.ev[4]); t.chain_ms = ms;
-    if (!detect) {
-        (void)hipEventElapsedTime(&ms, sl.ev[4], sl.ev[5]); t.paymf_ms = ms;
-        (void)hipEventElapsedTime(&ms, sl.ev[5], sl.ev[6]); t.paypll_ms = ms;
-        (void)hipEventElapsedTime(&ms, sl.ev[6], sl.ev[7]); t.paydec_ms = ms;
+    if (sl.timing_level >= 2) {
+        (void)hipEventElapsedTime(&ms, sl.ev[0], sl.ev[1]); t.walk_ms = ms;
+        (void)hipEventElapsedTime(&ms, sl.ev[1], sl.ev[2]); t.seekverify_ms = ms;
+        (void)hipEventElapsedTime(&ms, sl.ev[2], sl.ev[4]); t.chain_ms = ms;
+        if (!detect) {
+            (void)hipEventElapsedTime(&ms, sl.ev[4], sl.ev[5]); t.paymf_ms = ms;
+            (void)hipEventElapsedTime(&ms, sl.ev[6], sl.ev[7]); t.paydec_ms = ms;
+        }
     }
+    if (sl.timing_level >= 1 && !detect) { (void)hipEventElapsedTime(&ms, sl.ev[5], sl.ev[6]); t.paypll_ms = ms; }
     t.total_ms = t.walk_ms + t.seekverify_ms + t.chain_ms + t.paymf_ms + t.paypll_ms + t.paydec_ms;
     t.hops = h.hops + sl.kept_hops; t.hops_cheap = h.hops_cheap + sl.kept_cheap; t.walk_jobs = sl.NJ; t.repairs = h.repairs + sl.kept_repairs + h.n_repair_req; t.frames = h.n_frames;
     t.payload_symbols = h.sym_total; t.verify_hops = h.verify_hops + sl.kept_vhops; t.verify_failures = h.verify_failures + sl.kept_vfail;

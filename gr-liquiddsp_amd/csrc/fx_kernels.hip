@@ -231,10 +231,296 @@ template <class LDS> __device__ __forceinline__ void decode_header_bytes(LDS &L,
     __syncthreads();
 }
 
+// ===================================================================== detector-only walker (frame_detector_cc): a wave per hop
+// In detector mode every hop costs the full sweep (1 forward + 49 inverse FFT-512 + the winner's lag), and a hop is a pure
+// function of (pos, floor).  Between two detections the hop grid is known in advance, so a workgroup takes as many hops as it has
+// waves at a time and every wave runs ONE WHOLE HOP by itself: its own forward transform (no wave idles meanwhile), the window's
+// spectrum kept in registers in natural order for all 49 bins (no LDS round trip for it), all 49 bins (no 49 = 6 x 8 + 1 tail),
+// no workgroup barrier between the window load and the verdicts.  The first hop of the round that fires is aligned by the whole
+// workgroup exactly as before; the hops behind it are discarded (the grid restarts at the detection).  Same arithmetic per
+// transform, same tie rules (first maximum in (bin, lag) order) as seek_sweep(): bit-identical decisions.
+template <int WW> struct DetLdsT {
+    static constexpr int WAVES = WW;
+    float2 S[FX_NFFT];                  // template spectrum
+    float2 cw[(WW + 1) * FX_HOP];       // samples [pos - 256, pos + 256 WW); ALIGN: win = cw[0, 512), X = cw[512, 1024), P = cw[1024, 1280)
+    float2 scr[WW][576];                // per-wave FFT exchange buffers (ALIGN: m2 borrows scr[1])
+    float2 redc[4];
+    float  f[16]; uint32_t u[16];
+    float  pk[WW]; uint32_t bi[WW]; int bo[WW]; uint32_t dt[WW];
+};
+static_assert(FX_DETECT_WAVES >= 4, "ALIGN borrows cw[0, 1280) and scr[1]");
+
+// the canonical half-window energy (block_sum256's order) by one wave: elements 64 q + lane, q = 0..3
+__device__ __forceinline__ float half_energy_wave(const float2 *h, int lane)
+{
+    const float s0 = wave_sum(cm2(h[lane])), s1 = wave_sum(cm2(h[64 + lane])), s2 = wave_sum(cm2(h[128 + lane])), s3 = wave_sum(cm2(h[192 + lane]));
+    return (s0 + s1) + (s2 + s3);
+}
+
+// one detector hop by ONE wave: w = its 512-sample window in LDS, scr = its exchange buffer (576 float2)
+__device__ __forceinline__ bool seek_sweep_wave(const float2 *w, const float2 *S, float2 *scr, float threshold, float s2sum, const float2 (&twA)[7],
+                                                const float2 (&twB)[7], int lane, uint32_t &bidx, int &boff, float &peak)
+{
+    const float x2_0 = half_energy_wave(w, lane), x2_1 = half_energy_wave(w + FX_HOP, lane);
+    const float g0 = sqrtf(x2_0 + x2_1) * sqrtf((float)FX_S_LEN / (float)FX_NFFT);
+    bidx = 0; boff = 0; peak = 0.0f;
+    if (g0 < 1e-10f) return false;
+    float2 a[8], xn[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) a[q] = w[lane + 64 * q];
+    fft512_wave(a, scr, lane, twA, twB);
+    {   // spectrum into natural order, into registers: lane j keeps X[j + 64 q]
+        const int kb = (lane >> 3) + 8 * (lane & 7);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 8; t++) scr[kb + 64 * t] = a[t];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 8; q++) xn[q] = scr[lane + 64 * q];
+        __builtin_amdgcn_wave_barrier();
+    }
+    float bv = -1.0f; uint32_t bo = 0xFFFFFFFFu;
+#pragma unroll 1
+    for (int off = -FX_RANGE; off <= FX_RANGE; off++) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const float2 y = cmulc(xn[q], S[(lane + 64 * q - off) & (FX_NFFT - 1)]);
+            a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
+        }
+        fft512_wave(a, scr, lane, twA, twB);
+        float mo = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);     // |R|^2, R = (a.y, a.x)
+#pragma unroll
+        for (int t = 1; t < 8; t++) mo = fmaxf(mo, fmaf(a[t].y, a[t].y, a[t].x * a[t].x));
+        if (mo > bv) { bv = mo; bo = (uint32_t)(off + FX_RANGE); }          // bins ascend: first maximum kept
+        __builtin_amdgcn_wave_barrier();
+    }
+    wave_argmax(bv, bo);
+    const float g = 1.0f / ((float)FX_NFFT * g0 * sqrtf(s2sum));
+    peak = sqrtf(bv) * g;
+    boff = (int)bo - FX_RANGE;
+    if (!(peak > threshold)) return false;
+    // the winner's lag: first lag of bin bo whose |R|^2 equals the maximum
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const float2 y = cmulc(xn[q], S[(lane + 64 * q - boff) & (FX_NFFT - 1)]);
+        a[q] = make_float2(y.y, y.x);
+    }
+    fft512_wave(a, scr, lane, twA, twB);
+    uint32_t kmin = 0xFFFFFFFFu;
+    const uint32_t kb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+    for (int t = 7; t >= 0; t--) if (fmaf(a[t].y, a[t].y, a[t].x * a[t].x) == bv) kmin = kb + 64 * t;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) kmin = min(kmin, (uint32_t)__shfl_xor((int)kmin, m, 64));
+    bidx = kmin & (FX_NFFT - 1);
+    return bidx < FX_NFFT - FX_S_LEN;
+}
+
+template <int WW, bool EXT>
+__device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_index, FxWalkResult *result, FxFrame *frames, FxBlockHdr *hdr, const FxTables *T,
+                                           DetLdsT<WW> &L, const float2 (&twA)[7], const float2 (&twB)[7],
+                                           const FxWalkJob *all_jobs, const FxWalkResult *all_results, uint32_t n_jobs_total)
+{
+    constexpr int NT = 64 * WW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const XSrc xs = { job.x, job.xa_end, job.n };
+    const int64_t n = job.n;
+    int64_t pos = job.start, floor_ = job.floor, stop = job.stop;
+    int ext_left = 6;
+    bool fresh = job.fresh != 0, in_handoff = false, locked = job.prelock == 0;
+    uint32_t nfr = 0, hops = 0, exit_code = FX_EXIT_STOP, has_handoff = 0;
+    int64_t ho_start = 0, ho_pos = 0; int32_t ho_off = 0; float ho_rxy = 0.0f; uint32_t ho_clear = 0;
+    if (job.state_in) {
+        const FxStreamState st = *job.state_in;
+        if (st.invalid) {
+            if (tid == 0) {
+                FxWalkResult r; r.n_frames = 0; r.exit_code = FX_EXIT_INVALID; r.pos = 0; r.floor = 0; r.fresh = 1; r.has_handoff = 0;
+                r.handoff_start = 0; r.handoff_offset = 0; r.hops = 0; r.handoff_rxy = 0.0f; r.hops_cheap = 0; r.tail_pos = 0; r.tail_floor = 0;
+                r.handoff_pos = 0; r.handoff_clear = 0; r.tail_flags = FX_FLAG_SPAN_EXACT;
+                for (int i = 0; i < 4; i++) r.stamp[i] = 0;
+                *result = r;
+            }
+            return;
+        }
+        pos = st.pos; floor_ = st.floor; fresh = st.fresh != 0;
+    }
+    int64_t span_pos = pos, span_floor = floor_;
+    uint32_t span_flags = (fresh ? FX_FLAG_SEEK_FRESH : 0u) | FX_FLAG_SPAN_EXACT;
+    const float s2sum = T->s2sum;
+    const float2 *sc = T->sc;
+    const bool lo = tid < HALF;
+    float2 *win = L.cw, *X = L.cw + FX_NFFT, *P = L.cw + 2 * FX_NFFT; float *m2 = reinterpret_cast<float *>(L.scr[1]);
+
+    for (;;) {
+        pos = uniform64(pos); floor_ = uniform64(floor_);
+        nfr = __builtin_amdgcn_readfirstlane(nfr); hops = __builtin_amdgcn_readfirstlane(hops);
+        if (pos >= stop && !in_handoff) {
+            if (job.handoff && locked) in_handoff = true; else { exit_code = FX_EXIT_STOP; break; }
+        }
+        if (pos + FX_HOP > n) { exit_code = FX_EXIT_NEED_DATA; break; }
+        // hops of this round: on the grid pos + 256 h, inside the data, and -- unless this is the hand-off seek -- before the segment's end
+        int nh = (int)min((int64_t)WW, (n - pos) / FX_HOP);
+        if (!in_handoff) nh = (int)min((int64_t)nh, (stop - pos + FX_HOP - 1) / FX_HOP);
+        const int64_t fl0 = fresh ? max(floor_, pos) : floor_;        // (a freshly reset detector's overlap half is zeros)
+        __syncthreads();
+        for (int i = tid; i < (nh + 1) * FX_HOP; i += NT) L.cw[i] = xv(xs, pos - FX_HOP + i, i < FX_HOP ? fl0 : floor_);
+        __syncthreads();
+        if (wave < nh) {
+            uint32_t bidx; int boff; float peak;
+            const bool d = seek_sweep_wave(L.cw + FX_HOP * wave, L.S, L.scr[wave], job.threshold, s2sum, twA, twB, lane, bidx, boff, peak);
+            if (lane == 0) { L.dt[wave] = d ? 1u : 0u; L.bi[wave] = bidx; L.bo[wave] = boff; L.pk[wave] = peak; }
+        }
+        __syncthreads();
+        bool moved = false, leave = false;
+        for (int h = 0; h < nh; h++) {
+            hops++;
+            if (!L.dt[h]) continue;
+            const int64_t hp = pos + (int64_t)FX_HOP * h;              // this hop's position; what came before it in the round saw nothing
+            const uint32_t bidx = L.bi[h]; const int boff = L.bo[h]; const float peak = L.pk[h];
+            const int64_t a0 = hp - FX_HOP + (int64_t)bidx;
+            if (in_handoff) {
+                bool extend = false;
+                if constexpr (EXT) {
+                    if (ext_left > 0 && all_jobs) {
+                        uint32_t k = job_index + 1;                            // the segment the detection falls in (as fx_chain_kernel picks it)
+                        while (k + 1 < n_jobs_total && all_jobs[k + 1].stream == job.stream && a0 >= all_jobs[k].stop + FX_HOP) k++;
+                        if (k < n_jobs_total && all_jobs[k].stream == job.stream) {
+                            const FxFrame *FN = frames + all_jobs[k].frame_base;
+                            const uint32_t nfn = all_results[k].n_frames;
+                            int hit = 0;
+                            if (floor_ <= a0)
+                                for (uint32_t i = tid; i < nfn; i += NT) {
+                                    const uint32_t fl = FN[i].flags;
+                                    if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FN[i].start == a0 && FN[i].offset == boff) hit = 1;
+                                }
+                            hit = __syncthreads_or(hit);
+                            const int64_t room = (int64_t)job.max_frames - (int64_t)nfr - 8;
+                            if (!hit && room * FX_HOP > all_jobs[k].stop - a0) { extend = true; stop = all_jobs[k].stop; ext_left--; in_handoff = false; }
+                        }
+                    }
+                }
+                if (!extend) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = hp; ho_clear = floor_ <= a0 ? 1u : 0u; exit_code = FX_EXIT_STOP; pos = hp; fresh = fresh && h == 0; leave = true; break; }
+            }
+            if (nfr >= job.max_frames) { exit_code = FX_EXIT_TABLE_FULL; pos = hp; fresh = fresh && h == 0; leave = true; break; }
+            if (a0 + FX_NFFT > n) { exit_code = FX_EXIT_NEED_DATA; pos = hp; fresh = fresh && h == 0; leave = true; break; }
+            // Speculative walker not yet locked: a weak peak may be a false alarm the sequential chain never sees (its hop grid
+            // differs).  Ignore it and keep the grid; lock on a strong one.
+            if (!locked && !(peak > 0.7f)) continue;
+
+            // ------------------------------------------------------------ ALIGN on x[a0, a0+512): the whole workgroup
+            __syncthreads();
+            for (int i = tid; i < FX_NFFT; i += NT) win[i] = xv(xs, a0 + i, floor_);
+            __syncthreads();
+            if (wave == 0) {
+                float2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = win[lane + 64 * q];
+                fft512_wave(a, L.scr[0], lane, twA, twB);
+                const int kb = (lane >> 3) + 8 * (lane & 7);
+#pragma unroll
+                for (int t = 0; t < 8; t++) X[kb + 64 * t] = a[t];
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int i = lane + 64 * q;
+                    float2 y = cmulc(X[i], L.S[(i - boff) & (FX_NFFT - 1)]);
+                    a[q] = make_float2(y.y, y.x);
+                }
+                fft512_wave(a, L.scr[0], lane, twA, twB);
+                if (lane == 0)  L.f[0] = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);      // lags 0, +1, -1
+                if (lane == 8)  L.f[1] = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);
+                if (lane == 63) L.f[2] = fmaf(a[7].y, a[7].y, a[7].x * a[7].x);
+            }
+            __syncthreads();
+            float tau, gamma;
+            {
+                float y0 = sqrtf(sqrtf(L.f[0])), ypos = sqrtf(sqrtf(L.f[1])), yneg = sqrtf(sqrtf(L.f[2]));
+                float qa = 0.5f * (ypos + yneg) - y0, qb = 0.5f * (ypos - yneg);
+                tau = qa == 0.0f ? 0.0f : -qb / (2.0f * qa);
+                if (!(fabsf(tau) < 1.0f)) tau = 0.0f;
+                float gh = fmaf(fmaf(qa, tau, qb), tau, y0);
+                gamma = gh * gh / ((float)FX_NFFT * s2sum);
+            }
+            {
+                float2 p = make_float2(0.0f, 0.0f);
+                if (tid < FX_S_LEN) p = cmulc(win[tid], T->s[tid]);
+                if (lo) P[tid] = p;
+            }
+            __syncthreads();
+            if (wave == 0) {
+                float2 a[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) a[q] = (q < 4) ? P[lane + 64 * q] : make_float2(0.0f, 0.0f);
+                fft512_wave(a, L.scr[0], lane, twA, twB);
+                const uint32_t kb = (lane >> 3) + 8 * (lane & 7);
+                float bv = -1.0f; uint32_t bk = 0;
+#pragma unroll
+                for (int t = 0; t < 8; t++) {
+                    float m = cm2(a[t]);
+                    m2[kb + 64 * t] = m;
+                    if (m > bv) { bv = m; bk = kb + 64 * t; }
+                }
+                wave_argmax(bv, bk);
+                if (lane == 0) { L.f[3] = bv; L.u[0] = bk; }
+            }
+            __syncthreads();
+            float dphi;
+            {
+                const uint32_t i0 = L.u[0];
+                float v0 = sqrtf(L.f[3]);
+                float vneg = sqrtf(m2[(i0 + FX_NFFT - 1) & (FX_NFFT - 1)]);
+                float vpos = sqrtf(m2[(i0 + 1) & (FX_NFFT - 1)]);
+                float qa = 0.5f * (vpos + vneg) - v0, qb = 0.5f * (vpos - vneg);
+                float idx = qa == 0.0f ? 0.0f : -qb / (2.0f * qa);
+                float index = (float)i0 + idx;
+                dphi = (i0 > FX_NFFT / 2 ? index - (float)FX_NFFT : index) * (6.28318531f / (float)FX_NFFT);
+            }
+            const uint32_t mix_dl = rad2u32(dphi);
+            float phi;
+            {
+                float2 term = make_float2(0.0f, 0.0f);
+                if (tid < FX_S_LEN) term = derot(P[tid], mix_dl * (uint32_t)tid, sc);
+                float2 metric = block_csum256(term, L, lane, wave);
+                phi = atan2c(metric.y, metric.x);
+            }
+            FxFrameHead fr;
+            fr.start = a0; fr.offset = boff; fr.rxy = peak; fr.tau = tau; fr.gamma = gamma; fr.dphi = dphi; fr.phi = phi;
+            fr.seek_pos = span_pos; fr.seek_floor = span_floor; fr.det_pos = hp;
+            fr.pfb = 0; fr.mfc0 = 0; fr.mix_th = rad2u32(phi); fr.mix_dl = mix_dl; fr.mf_scale = 0.0f;
+            fr.pilot_dphi = fr.pilot_phi = fr.pilot_gain = 0.0f; fr.pll_th = 0; fr.pll_f = 0.0f;
+            fr.flags = (floor_ <= a0 ? FX_FLAG_FLOOR_CLEAR : 0u) | span_flags | FX_FLAG_EXACT;
+            fr.pay_len = fr.ms = fr.check = fr.fec0 = fr.fec1 = fr.pay_sym_len = 0;
+#pragma unroll
+            for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = 0;
+            locked = true;
+            fr.next = a0 + FX_NFFT;                                       // back to SEEK with the second half of the aligned window as overlap
+            if (tid == 0) static_cast<FxFrameHead &>(frames[job.frame_base + nfr]) = fr;
+            nfr++;
+            span_pos = a0 + FX_NFFT; span_floor = floor_; span_flags = FX_FLAG_SPAN_EXACT;
+            pos = a0 + FX_NFFT; fresh = false; moved = true;
+            break;
+        }
+        if (leave) break;
+        if (!moved) { pos += (int64_t)FX_HOP * nh; fresh = false; }
+    }
+
+    if (tid == 0) {
+        FxWalkResult r;
+        r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
+        r.has_handoff = has_handoff; r.handoff_start = ho_start; r.handoff_offset = ho_off; r.hops = hops;
+        r.handoff_rxy = ho_rxy; r.hops_cheap = 0;
+        r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos; r.handoff_clear = ho_clear;
+        r.tail_flags = span_flags;
+        for (int i = 0; i < 4; i++) r.stamp[i] = 0;
+        *result = r;
+        atomicAdd(&hdr->hops, hops); atomicAdd(&hdr->walk_jobs_run, 1u);
+    }
+}
+
 // MODE is a template parameter so that the detector-only instance (frame_detector_cc) carries none of the
 // header-recovery code or its registers.
 #ifndef FX_DETECT_OCC
-#define FX_DETECT_OCC 4      // waves per SIMD the detector-only instance is compiled for (2 or 4)
+#define FX_DETECT_OCC 3      // waves per SIMD the detector-only instance (and the seek verifier) is compiled for
 #endif
 #ifndef FX_FLEX_OCC
 #define FX_FLEX_OCC 2        // same for the flex_rx instance
@@ -816,12 +1102,24 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
     }
 }
 
+// the walker of a mode and its LDS layout: the detector-only mode has its own (detect_run, a wave per hop)
+template <int MODE, int WW> struct WalkLdsSel { typedef WalkLdsT<WW> type; };
+template <int WW> struct WalkLdsSel<FX_MODE_DETECT, WW> { typedef DetLdsT<WW> type; };
+template <int MODE, int WW, bool EQ, bool EXT = false>
+__device__ __forceinline__ void walk_any(const FxWalkJob &job, uint32_t job_index, FxWalkResult *result, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
+                                         FxBlockHdr *hdr, const FxTables *T, typename WalkLdsSel<MODE, WW>::type &L, const float2 (&twA)[7], const float2 (&twB)[7],
+                                         const FxWalkJob *all_jobs = nullptr, const FxWalkResult *all_results = nullptr, uint32_t n_jobs_total = 0)
+{
+    if constexpr (MODE == FX_MODE_DETECT) detect_run<WW, EXT>(job, job_index, result, frames, hdr, T, L, twA, twB, all_jobs, all_results, n_jobs_total);
+    else walk_run<MODE, WW, EQ, EXT>(job, job_index, result, frames, runs, run_cap, hdr, T, L, twA, twB, all_jobs, all_results, n_jobs_total);
+}
+
 template <int MODE, int WW, bool EQ, bool EXT = false>
 __global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
 void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
                     FxBlockHdr *hdr, const FxTables *T, uint32_t n_jobs_total, const uint32_t *n_list, uint32_t list_cap)
 {
-    __shared__ WalkLdsT<WW> L;
+    __shared__ typename WalkLdsSel<MODE, WW>::type L;
     const int tid = threadIdx.x, lane = tid & 63;
     if constexpr (EXT) {
         // the repair round enqueued with the block (fx_host.cpp:enqueue_back): how many segments are queued is only known on the
@@ -838,7 +1136,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResul
             for (uint32_t i = blockIdx.x; i < nreq; i += gridDim.x) {
                 const uint32_t ji = job_list[i] & 0x7fffffffu;
                 const FxWalkJob job = jobs[ji];
-                walk_run<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
+                walk_any<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
                 __syncthreads();
             }
             return;
@@ -846,7 +1144,7 @@ void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResul
     }
     const uint32_t ji = job_list[blockIdx.x] & 0x7fffffffu;
     const FxWalkJob job = jobs[ji];
-    walk_run<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
+    walk_any<MODE, WW, EQ, EXT>(job, ji, results + ji, frames, runs, run_cap, hdr, T, L, twA, twB, jobs, results, n_jobs_total);
 }
 
 // (the equaliser stage is a compile-time variant of the flex_rx walker: the default instance carries none of its code)
@@ -1228,7 +1526,7 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
                      const FxTables *T)
 {
     constexpr int NT = 64 * WW;
-    __shared__ WalkLdsT<WW> L;
+    __shared__ typename WalkLdsSel<MODE, WW>::type L;
     __shared__ ChainLds C;
     const uint32_t s = blockIdx.x;
     const FxStreamDesc sd = streams[s];
@@ -1263,7 +1561,7 @@ void fx_chain_kernel(const FxStreamDesc *streams, const FxWalkJob *jobs, uint32_
                 j.start = wst; j.floor = wfl; j.fresh = wfr ? 1u : 0u; j.prelock = 0; j.no_skip = 1; j.state_in = nullptr;
                 j.frame_base = sd.repair_base; j.max_frames = sd.repair_cap;
                 __syncthreads();
-                walk_run<MODE, WW, EQ>(j, wj, rep_res, frames, runs, run_cap, hdr, T, L, twA, twB);
+                walk_any<MODE, WW, EQ>(j, wj, rep_res, frames, runs, run_cap, hdr, T, L, twA, twB);
                 wg_sync_global();
                 if (tid == 0) atomicAdd(&hdr->repairs, 1u);
                 Rp = rep_res; F = frames + sd.repair_base; m = 0; need_walk = false;
@@ -1677,11 +1975,7 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
                      const FxTables *T)
 {
     constexpr int LEAD = EQ ? FX_EQ_TAPS - 1 : 0;
-    // the mixed-down span.  Without the equaliser it is kept de-interleaved -- even samples in ve[], odd ones in vo[] (v[m] =
-    // (m & 1 ? vo : ve)[m >> 1]) --: a symbol's taps alternate between the two, and neighbouring lanes, whose symbols sit two
-    // samples apart, then read neighbouring entries of each instead of every other one.
-    __shared__ float2 v[EQ ? PMF_SPAN + LEAD + 4 : 2];
-    __shared__ float2 ve[EQ ? 2 : (PMF_SPAN + 8) / 2 + 4], vo[EQ ? 2 : (PMF_SPAN + 8) / 2 + 4];
+    __shared__ float2 v[PMF_SPAN + LEAD + 4];
     __shared__ float2 u[EQ ? 2 * PMF_SYMS + FX_EQ_TAPS : 1];
     __shared__ float2 eqw[16];
     __shared__ float taps[FX_MF_TAPS];
@@ -1702,8 +1996,7 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
         if (EQ && tid < 16) eqw[tid] = tid < FX_EQ_TAPS ? chain[job.chain_idx].eq[tid] : make_float2(0.0f, 0.0f);
         for (int m = tid; m < span; m += PMF_THREADS) {
             const int64_t nn = nlo + m;                            // (nn >= 0: a payload symbol is hundreds of samples into the frame)
-            const float2 w = derot(xld(xs, job.start + nn), job.mix_th + job.mix_dl * (uint32_t)nn, sc);
-            if constexpr (EQ) v[m] = w; else (m & 1 ? vo : ve)[m >> 1] = w;
+            v[m] = derot(xld(xs, job.start + nn), job.mix_th + job.mix_dl * (uint32_t)nn, sc);
         }
         __syncthreads();
         if (EQ) {
@@ -1723,30 +2016,93 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
                 sym_raw[(size_t)job.sym_off + c0 + i] = eq_sum16(u + nc - (FX_EQ_TAPS - 1), eqw);
             }
         } else {
-            // two neighbouring symbols per thread (their 28-tap windows share 26 samples), one 16-byte store; each symbol's sum
-            // runs over its taps in ascending order, as everywhere.  (An odd last symbol computes a phantom neighbour into the
-            // padding of the frame's 8-symbol granule.)
-            static_assert(FX_MF_TAPS == 28, "tap loop below is written for 28 taps");
-            for (uint32_t j = tid; 2u * j < ns; j += PMF_THREADS) {
-                const uint32_t i0 = 2u * j;
-                const int nc0 = (int)(sym_sample(sym0 + c0 + i0, job.mfc0) - nlo);       // symbol i0 at span sample nc0, symbol i0 + 1 at nc0 + 2
-                const float2 *pa = (nc0 & 1) ? vo : ve, *pb = (nc0 & 1) ? ve : vo;       // samples of nc0's parity (even taps) / the other (odd taps)
-                const int ka = (nc0 >> 1) + 1, kb = ((nc0 - 1) >> 1) + 1;
-                float2 ea[15], ob[15];
-#pragma unroll
-                for (int k = 0; k < 15; k++) { ea[k] = pa[ka - k]; ob[k] = pb[kb - k]; }
-                float a0r = 0.0f, a0i = 0.0f, a1r = 0.0f, a1i = 0.0f;
-#pragma unroll
-                for (int h = 0; h < 14; h++) {
-                    const float h0 = taps[2 * h], h1 = taps[2 * h + 1];
-                    a0r = fmaf(h0, ea[h + 1].x, a0r); a0i = fmaf(h0, ea[h + 1].y, a0i);
-                    a0r = fmaf(h1, ob[h + 1].x, a0r); a0i = fmaf(h1, ob[h + 1].y, a0i);
-                    a1r = fmaf(h0, ea[h].x, a1r); a1i = fmaf(h0, ea[h].y, a1i);
-                    a1r = fmaf(h1, ob[h].x, a1r); a1i = fmaf(h1, ob[h].y, a1i);
+            for (uint32_t i = tid; i < ns; i += PMF_THREADS) {
+                const int nc = (int)(sym_sample(sym0 + c0 + i, job.mfc0) - nlo);
+                float ar = 0.0f, ai = 0.0f;
+#pragma unroll 7
+                for (int t = 0; t < FX_MF_TAPS; t++) {
+                    const float2 w = v[nc - t]; const float h = taps[t];
+                    ar = fmaf(h, w.x, ar); ai = fmaf(h, w.y, ai);
                 }
-                *reinterpret_cast<float4 *>(sym_raw + (size_t)job.sym_off + c0 + i0) =
-                    make_float4(a0r * job.mf_scale, a0i * job.mf_scale, a1r * job.mf_scale, a1i * job.mf_scale);
+                sym_raw[(size_t)job.sym_off + c0 + i] = make_float2(ar * job.mf_scale, ai * job.mf_scale);
             }
+        }
+    }
+}
+
+// The matched filter proper (no equaliser): four consecutive symbols per thread.  A symbol is 28 taps over samples two apart from
+// its neighbour's, so four symbols share all but six of their samples: 34 LDS reads instead of 112, and the kernel -- which was
+// bound by exactly those reads (56 two-way-conflicted ds_read_b64 per symbol) -- becomes a stream of the IQ through the mixer.
+// Layout that makes the register tile conflict-free: with the item's first symbol at span sample 27, symbol i is
+//     y[i] = sum_k h[2k] vo[13 + i - k] + h[2k+1] ve[13 + i - k],     ve[j] = v[2j], vo[j] = v[2j+1]
+// (summed over the taps in ascending order, as everywhere); thread t, symbols 4t..4t+3, needs ve/vo[4t .. 4t+16].  Both are
+// kept de-interleaved by four -- ve[j] at VE[j & 3][j >> 2] -- so that every load of the tile is "phase array p, entry
+// t + const": consecutive lanes, consecutive 8-byte words.  The eight phase arrays sit PMF4_STRIDE entries apart, chosen so
+// that the 16 lanes of a staging store (8 arrays x 2 entries) fall into 32 different banks.
+#define PMF4_STRIDE 274
+extern "C" __global__ __launch_bounds__(PMF_THREADS)
+void fx_paymf4_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr, float2 *sym_raw, const FxTables *T)
+{
+    __shared__ float2 ph[8 * PMF4_STRIDE];                          // [parity * 4 + phase][entry]
+    __shared__ __attribute__((aligned(16))) float taps[FX_MF_TAPS];
+    static_assert(FX_MF_TAPS == 28 && PMF_SYMS == 4 * PMF_THREADS, "tile below: 28 taps, four symbols per thread");
+    static_assert(PMF4_STRIDE >= (PMF_SPAN + 8) / 8 + 5, "phase arrays hold the span plus the slack phantom symbols read");
+    const uint32_t nitems = hdr->n_mfblk;
+    const int tid = threadIdx.x;
+    const float2 *sc = T->sc;
+    for (uint32_t bi = blockIdx.x; bi < nitems; bi += gridDim.x) {
+        const FxPayJob job = jobs[blk_job[bi]];
+        const uint32_t c0 = blk_c0[bi];                            // first payload symbol of this item
+        const uint32_t ns = min((uint32_t)PMF_SYMS, job.nsym - c0);
+        const int64_t nlo = sym_sample((int64_t)FX_SYM0_PAY + c0, job.mfc0) - (FX_MF_TAPS - 1);     // span sample 0; the item's symbol i at span sample 27 + 2 i
+        const int span = 2 * (int)ns + (FX_MF_TAPS - 2);
+        const float2 *px = job.x, *pa = job.xa_end;
+        const int64_t p0 = job.start + nlo;                       // stream index of span sample 0 (>= floor: a payload symbol is hundreds of samples into the frame)
+        const uint32_t th0 = job.mix_th + job.mix_dl * (uint32_t)nlo, dl = job.mix_dl;
+        __syncthreads();
+        if (tid < FX_MF_TAPS) taps[tid] = T->proto[job.pfb + FX_NPFB * tid];
+        // the span (at most 2074 samples: nine per thread), every load issued before the first one is needed -- a rolled loop of
+        // load / wait / mix / store left one 8-byte load per thread in flight and the kernel waiting on memory latency 2/3 of its time
+        constexpr int NLD = (PMF_SPAN + PMF_THREADS - 1) / PMF_THREADS;
+        float2 raw[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int m = tid + PMF_THREADS * k;
+            const int64_t p = p0 + m;
+            raw[k] = m < span ? (p < 0 ? pa[p] : px[p]) : make_float2(0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; k++) {
+            const int m = tid + PMF_THREADS * k;
+            const int j = m >> 1;
+            if (m < span) ph[((m & 1) * 4 + (j & 3)) * PMF4_STRIDE + (j >> 2)] = derot(raw[k], th0 + dl * (uint32_t)m, sc);
+        }
+        __syncthreads();
+        if (4u * (uint32_t)tid < ns) {
+            float2 e[17], o[17];
+#pragma unroll
+            for (int j = 0; j < 17; j++) {
+                e[j] = ph[(j & 3) * PMF4_STRIDE + tid + (j >> 2)];
+                o[j] = ph[(4 + (j & 3)) * PMF4_STRIDE + tid + (j >> 2)];
+            }
+            float h[FX_MF_TAPS];
+#pragma unroll
+            for (int q = 0; q < FX_MF_TAPS / 4; q++) { const float4 t4 = reinterpret_cast<const float4 *>(taps)[q]; h[4 * q] = t4.x; h[4 * q + 1] = t4.y; h[4 * q + 2] = t4.z; h[4 * q + 3] = t4.w; }
+            float yr[4], yi[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                float ar = 0.0f, ai = 0.0f;
+#pragma unroll
+                for (int k = 0; k < 14; k++) {                      // taps 2k (odd-sample array), 2k + 1 (even-sample array): ascending tap order
+                    ar = fmaf(h[2 * k], o[13 + r - k].x, ar); ai = fmaf(h[2 * k], o[13 + r - k].y, ai);
+                    ar = fmaf(h[2 * k + 1], e[13 + r - k].x, ar); ai = fmaf(h[2 * k + 1], e[13 + r - k].y, ai);
+                }
+                yr[r] = ar * job.mf_scale; yi[r] = ai * job.mf_scale;
+            }
+            // (sym_off is a multiple of 8 symbols, c0 of 1024: 32-byte aligned; symbols beyond ns land in the padding of the frame's granule)
+            float4 *dst = reinterpret_cast<float4 *>(sym_raw + (size_t)job.sym_off + c0 + 4u * (uint32_t)tid);
+            dst[0] = make_float4(yr[0], yi[0], yr[1], yi[1]);
+            dst[1] = make_float4(yr[2], yi[2], yr[3], yi[3]);
         }
     }
 }
@@ -1756,7 +2112,7 @@ extern "C" hipError_t fx_launch_paymf(unsigned grid, int eq, hipStream_t st, con
 {
     if (grid == 0) return hipSuccess;
     if (eq) hipLaunchKernelGGL(fx_paymf_kernel<true>, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, chain, sym_raw, T);
-    else hipLaunchKernelGGL(fx_paymf_kernel<false>, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, chain, sym_raw, T);
+    else hipLaunchKernelGGL(fx_paymf4_kernel, dim3(grid), dim3(PMF_THREADS), 0, st, jobs, blk_job, blk_c0, hdr, sym_raw, T);
     return hipGetLastError();
 }
 
@@ -2578,12 +2934,10 @@ void fx_paydec_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBlo
     // The list's length is known on the device only.  The lean instance has no loop around its body (a grid-stride loop
     // doubles the register footprint): the host launches it over the list's capacity -- a grid sized from the previous block
     // plus a second, normally idle one for the rest -- and surplus waves leave at once.  The Reed-Solomon instance strides.
-    // (fallback_host set: the list is that of the frames the batch Viterbi path handed back, and its length is passed on to
-    // the host's copy of the header, for fxrx_collect to see whether this launch covered it)
+    // (fallback_host set: the list is that of the frames the batch Viterbi path handed back)
     __shared__ __attribute__((aligned(16))) uint8_t Xs[WITH_RS ? 16 : DEC_LDS];   // (the lean instance, one wave per workgroup: staging for the de-interleaver)
     uint8_t *X = (!WITH_RS && blockDim.x == 64) ? Xs : nullptr;
     const uint32_t njobs = WITH_RS ? hdr->n_dec_rs : (fallback_host ? hdr->n_vb_fallback : hdr->n_dec_plain);
-    if (!WITH_RS && fallback_host && first_wave == 0 && blockIdx.x == 0 && threadIdx.x == 0) fallback_host->n_vb_fallback = njobs;
     const uint32_t wpg = blockDim.x >> 6;
     const int lane = threadIdx.x & 63;
     const uint32_t ji0 = __builtin_amdgcn_readfirstlane(first_wave + blockIdx.x * wpg + (threadIdx.x >> 6));
@@ -2752,13 +3106,12 @@ __device__ __forceinline__ void vb_forward(const uint8_t *enc, int p, uint32_t t
         const unsigned long long d1 = vb_step(N, P, pa, pb, up, col, nb, w0, w1, wbase, run);
         // (regions are an even number of steps long within the slab: step ur + 1 is inside it whenever ur is)
         const uint32_t ur = u - reg_at, t = t_reg + ur;
-        if (lane_on && u >= reg_at && t < t1) { dwl[(size_t)ur * 64u] = d0; dwl[(size_t)(ur + 1u) * 64u] = d1; }
+        if (lane_on && u >= reg_at && t < t1) { __builtin_nontemporal_store(d0, dwl + (size_t)ur * 64u); __builtin_nontemporal_store(d1, dwl + (size_t)(ur + 1u) * 64u); }
     }
     if (lane_on && end_vec) vb_save_vec(P, end_vec);
 }
 
 // per work item, after the forward pass: [7:0] the end state its traceback started from, [15:8] the state it arrived at
-#define VB_ST_BAD 0x10000u        // the block's start differences are not the end differences of the block before it
 #define VB_ST_REP 0x20000u        // ... were not: the block has been run again from the true ones
 static_assert(FX_VB_WARM <= 128, "trellis blocks are at least 128 steps: a block's warm-up must fit into the block before it");
 // warm-up steps by puncturing period: the rate-1/2 code merges fastest; the high-rate punctured codes (5/6, 6/7, 7/8) carry
@@ -2918,8 +3271,10 @@ __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A
         vb2_step(N, Q, pa, pb, up, sa, sb, run_a, run_b, a1, b1);
         // (regions are an even number of steps long within the slab: step ur + 1 is inside it whenever ur is)
         const uint32_t ur = u - warm;
-        if (A.on && in_reg && A.t_reg + ur < A.t1) { A.dwl[(size_t)ur * 64u] = a0; A.dwl[(size_t)(ur + 1u) * 64u] = a1; }
-        if (B.on && in_reg && B.t_reg + ur < B.t1) { B.dwl[(size_t)ur * 64u] = b0; B.dwl[(size_t)(ur + 1u) * 64u] = b1; }
+        // (decision words stream through -- written once, read once by the traceback --: non-temporal, so that they do not push the
+        // coded bits, which every lane comes back to sixteen steps later, out of the L2)
+        if (A.on && in_reg && A.t_reg + ur < A.t1) { __builtin_nontemporal_store(a0, A.dwl + (size_t)ur * 64u); __builtin_nontemporal_store(a1, A.dwl + (size_t)(ur + 1u) * 64u); }
+        if (B.on && in_reg && B.t_reg + ur < B.t1) { __builtin_nontemporal_store(b0, B.dwl + (size_t)ur * 64u); __builtin_nontemporal_store(b1, B.dwl + (size_t)(ur + 1u) * 64u); }
     }
     if (A.on) vb2_save_vec(Q, 0, A.vec + 64);
     if (B.on) vb2_save_vec(Q, 1, B.vec + 64);
@@ -3001,30 +3356,11 @@ __device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
     return same;
 }
 
-// ---- hand-over check: a block whose warm-up did not arrive at the true metric differences runs again from them ----
-// (same lanes as the forward pass; a wave without such a block leaves at once.  Should the block before it be run again as
-// well and end differently -- a repair behind a repair -- the check in fx_vbtrace_kernel still fails and the frame goes to
-// the wave-per-frame decoder: results never rest on an unverified hand-over.)
-extern "C" __global__ __launch_bounds__(64)
-void fx_vbfix_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
-                     unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
-{
-    const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
-    const uint32_t it0 = first_item + blockIdx.x * 64u;
-    if (it0 >= nitems) return;
-    const uint32_t slot = it0 + threadIdx.x;
-    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
-    uint8_t *vec = vec_arena + (size_t)slot * 128u;
-    // (dbg bit 1, tests only: every other failing block is left as it is, for the fallback path to be exercised)
-    const bool bad = it.on && it.b > 0 && !vb_same64(vec, vec - 64) && !((dbg & 2u) && (slot & 1u));
-    const unsigned long long fails = __ballot(bad);
-    if (!fails) return;
-    const FxPayJob &job = jobs[it.g];
-    const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)fails) - 1, 64));
-    vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, 2, bad ? vec - 64 : vec, vb_slab(dwv, slot, blk), vec, vec + 64, blk, 0u, bad);
-    if (bad) vb_st[slot] = VB_ST_REP | vb_make_guess(vb_slab(dwv, slot, blk), it.t1 - it.t_reg);   // (fx_vbfinish_kernel counts these; the guess: from the new decisions)
-}
-
+// ---- hand-over check (first thing fx_vbtrace_kernel does): a block whose warm-up did not arrive at the true metric differences
+// -- its start record differs from the end record of the block before it -- runs again from them, by the lane that is about to
+// trace it back.  No ordering between lanes is assumed: the block before may itself be running again at that moment and end
+// differently.  Results never rest on that: fx_vbfinish_kernel compares, for every block of a frame, the FINAL start record with
+// the FINAL end record of its predecessor and hands the frame to the wave-per-frame decoder if any pair differs.
 // sixteen traceback steps u0 + 15 .. u0 of one lane (those below lim only): the words first, then the chain through them
 __device__ __forceinline__ void vb_trace16(const unsigned long long *dwl, uint32_t u0, uint32_t lim, unsigned &st, uint32_t &bits16)
 {
@@ -3069,8 +3405,8 @@ __device__ __forceinline__ unsigned vb_trace_chunk(const unsigned long long *dwl
 // next block from state 0 (the survivors of all states merge within a few constraint lengths) and starts from where that
 // arrives.  fx_vbfinish_kernel checks that guess against the state the next block's traceback really arrived at.
 extern "C" __global__ __launch_bounds__(64)
-void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, uint8_t *bufA,
-                       unsigned long long *dwv, const uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, uint8_t *bufA, const uint8_t *bufB,
+                       unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
 {
     const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
     const uint32_t it0 = first_item + blockIdx.x * 64u;
@@ -3080,16 +3416,24 @@ void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t 
     if (!__ballot(it.on)) return;
     const FxPayJob &job = jobs[it.g];
     const uint32_t len = it.on ? it.t1 - it.t_reg : 0u;
-    uint32_t flags = it.on ? (vb_st[slot] & VB_ST_REP) : 0u;
-    const uint8_t *vec = vec_arena + (size_t)slot * 128u;
-    if (it.on && it.b > 0 && !vb_same64(vec, vec - 64)) flags |= VB_ST_BAD;
+    uint32_t old = it.on ? vb_st[slot] : 0u;
+    uint32_t flags = 0u;
+    uint8_t *vec = vec_arena + (size_t)slot * 128u;
+    unsigned long long *dwl = vb_slab(dwv, slot, blk);
+    {   // hand-over check (dbg bit 1, tests only: every other failing block is left as it is, for the fallback path to be exercised)
+        const bool bad = it.on && it.b > 0 && !vb_same64(vec, vec - 64) && !((dbg & 2u) && (slot & 1u));
+        const unsigned long long fails = __ballot(bad);
+        if (fails) {
+            const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)fails) - 1, 64));
+            vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, 2, bad ? vec - 64 : vec, dwl, vec, vec + 64, blk, 0u, bad);
+            if (bad) { flags |= VB_ST_REP; old = (old & ~0x3F000000u) | vb_make_guess(dwl, len); }      // (fx_vbfinish_kernel counts these; the guess: from the new decisions)
+        }
+    }
     // the end state: 0 behind the flushed tail; elsewhere the guess the next block's forward pass left (its first FX_VB_TWARM
     // steps traced back from state 0)
     const bool has_next = it.on && it.b + 1u < it.nblk;
     // (dbg bit 0, tests only: the guess is state 0 -- wrong 63 times in 64, for the re-trace path to be exercised)
-    const uint32_t old = it.on ? vb_st[slot] : 0u;
     const unsigned S = (has_next && !(dbg & 1u)) ? ((vb_st[slot + 1u] >> 24) & 63u) : 0u;
-    const unsigned long long *dwl = vb_slab(dwv, slot, blk);
     uint8_t *A = bufA + job.byte_off + it.t_reg / 8u;
     unsigned st = S;
     for (int c = (int)(blk / 64u) - 1; c >= 0; c--) {
@@ -3204,12 +3548,26 @@ void fx_vbpre_kernel(const FxPayJob *jobs, const uint32_t *job_idx, const FxBloc
 // ---- back part, one wave per frame: the chain of traceback states across the frame's blocks, then the frame's tail ----
 extern "C" __global__ __launch_bounds__(64)
 void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr, uint32_t first_wave, uint8_t *bufA, uint8_t *bufB,
-                        unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap, uint8_t *out, FxOutRec *recs)
+                        unsigned long long *dwv, const uint8_t *vec_arena, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap, uint8_t *out, FxOutRec *recs,
+                        FxBlockHdr *hdr_host)
 {
     const uint32_t njobs = hdr->n_dec_batch, blk = hdr->vb_blk;
     const uint32_t ji = first_wave + blockIdx.x;
     if (ji >= njobs) return;
     const int lane = threadIdx.x & 63;
+    // the wave that finishes last tells the host how many frames were handed back (fxrx_collect decodes them the other way if the
+    // chain did not): waves of this launch that have a frame = min(njobs, first_wave + grid) - first_wave
+    auto done = [&]() {
+        __threadfence();
+        if (lane == 0) {
+            const uint32_t mine = min(njobs, first_wave + gridDim.x) - first_wave;
+            if (atomicAdd(&hdr->vb_ticket, 1u) == mine - 1u) {
+                __threadfence();
+                hdr_host->n_vb_fallback = __hip_atomic_load(&hdr->n_vb_fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hdr->vb_ticket = 0u;
+            }
+        }
+    };
     const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
     job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
@@ -3221,12 +3579,14 @@ void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHd
     for (uint32_t base = 0; base < nblk; base += 64) {
         const uint32_t b = base + (uint32_t)lane;
         const uint32_t v = b < nblk ? vb_st[at + b] : 0u, vn = b + 1u < nblk ? vb_st[at + b + 1u] : 0u;
-        bad = bad || (v & VB_ST_BAD);
+        // every hand-over, on the records as they stand now: block b started from what block b - 1 ended with
+        if (b > 0 && b < nblk) { const uint8_t *vec = vec_arena + (size_t)(at + b) * 128u; bad = bad || !vb_same64(vec, vec - 64); }
         rep += (uint32_t)__popcll(__ballot((v & VB_ST_REP) != 0u));
         mism = mism || (b + 1u < nblk && (v & 0xffu) != ((vn >> 8) & 0xffu));
     }
     if (__any(bad)) {                                                       // an unverified hand-over: the frame is decoded the other way
         if (lane == 0) { const uint32_t s = atomicAdd(&hdr->n_vb_fallback, 1u); if (s < list_cap) fb_list[s] = jf; }
+        done();
         return;
     }
     if (__any(mism)) {                                                      // a wrong end-state guess: from the last block downwards
@@ -3240,6 +3600,7 @@ void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHd
     (void)Tn;
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     dec_tail(job, jf, A, lane, out, recs, rep << 8);
+    done();
 }
 
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
@@ -3249,7 +3610,7 @@ extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hip
     hipLaunchKernelGGL(fx_vbpre_kernel, dim3(n_waves), dim3(DEC_THREADS), 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, T);
     return hipGetLastError();
 }
-// forward pass, hand-over check, traceback: the three lane-per-work-item kernels, over the same item slots
+// forward pass and traceback (with the hand-over check in front): the two lane-per-work-item kernels, over the same item slots
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
                                         const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed)
 {
@@ -3257,19 +3618,15 @@ extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, h
     const dim3 grid((n_items + 63) / 64), block(64);
     if (!packed) hipLaunchKernelGGL(fx_vbfwd1_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
     else hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 127) / 128), block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
-    // (twice: a block run again may end differently, and then the block behind it has to be run again as well; what two passes
-    // do not settle goes to the wave-per-frame decoder)
-    hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);
-    hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);
-    hipLaunchKernelGGL(fx_vbtrace_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufA, dwv, vec_arena, vb_st, dbg);
+    hipLaunchKernelGGL(fx_vbtrace_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufA, bufB, dwv, vec_arena, vb_st, dbg);
     return hipGetLastError();
 }
 extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
-                                         uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
-                                         uint8_t *out, FxOutRec *recs)
+                                         uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint8_t *vec_arena, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
+                                         uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_host)
 {
     if (n_waves == 0) return hipSuccess;
-    hipLaunchKernelGGL(fx_vbfinish_kernel, dim3(n_waves), dim3(64), 0, st, jobs, job_idx, hdr, first_wave, bufA, bufB, dwv, vb_st, fb_list, list_cap, out, recs);
+    hipLaunchKernelGGL(fx_vbfinish_kernel, dim3(n_waves), dim3(64), 0, st, jobs, job_idx, hdr, first_wave, bufA, bufB, dwv, vec_arena, vb_st, fb_list, list_cap, out, recs, hdr_host);
     return hipGetLastError();
 }
 

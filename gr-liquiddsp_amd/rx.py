@@ -69,6 +69,11 @@ class RxContext:
         if self.L.fxrx_set_depth(self.h, depth) != 0:
             raise RxError("fxrx_set_depth failed: %s" % self.L.fxrx_last_error().decode())
 
+    def set_timing(self, level):
+        """Stage events per block: 2 all stages, 1 the PLL only, 0 none, -1 automatic (see include/fxrx.h: fxrx_set_timing)."""
+        if self.L.fxrx_set_timing(self.h, int(level)) != 0:
+            raise RxError("fxrx_set_timing: bad level")
+
     def submit_raw(self, ptrs, counts, on_device):
         n = self.n_streams
         a = (C.c_void_p * n)(*ptrs)

@@ -235,6 +235,14 @@ typedef struct {
     uint64_t vb_fallbacks;                       /* batch Viterbi: frames handed back to the wave-per-frame decoder (a hand-over that stayed unverified) */
 } fxrx_timing;
 int fxrx_last_timing(const fxrx_ctx *c, fxrx_timing *t);
+/* Stage times come from HIP events recorded between the kernels of a block, and every event is one more packet in the block's
+ * queue -- with blocks in flight the queues' packet rate is what limits throughput.  level 2: all stages;
+ * 1: the PLL only (paypll_ms; what bench.py quotes its roofline line for); 0: none (the *_ms fields read 0); -1 (default):
+ * 2 with one block at a time, 0 with depth > 1.  Counters are always there.  Environment: FXRX_TIMING. */
+int fxrx_set_timing(fxrx_ctx *c, int level);
+/* diagnostics: of the last collected block, ms since a common origin: host time at fxrx_submit, GPU time of its first and of its
+ * last event, host time when fxrx_collect returned it (needs timing level 2 from the first submit on) */
+int fxrx_debug_block_times(const fxrx_ctx *c, double out[4]);
 /* the HIP stream (hipStream_t as void*) of the first slot of the ring of blocks in flight; every block runs its whole kernel
  * chain on its slot's stream.  To order external work against a block, use fxrx_collect (it returns when the block's
  * results are on the host). */

@@ -39,8 +39,8 @@ x, inj = fx.synth_stream(20_000_000, stream_id=0)
 n = len(x) - len(x) % 256
 F = fx._ffi.feed_lib()
 print("copy-only ceiling (256-sample memcpy into pinned memory): %.0f Msamples/s" % (F.dropin_copy_ceiling(x.ctypes.data, n, 1 << 20, 3) / 1e6), flush=True)
-for blk in (1 << 18, 1 << 20, 1 << 21):
-    for depth in (3, 4, 6):
+for blk in (1 << 20, 1 << 21):
+    for depth in (3, 4):
         os.environ["FXRX_SYNC_BLOCK"] = str(blk); os.environ["FXRX_SYNC_DEPTH"] = str(depth)
         F.dropin_feed(x.ctypes.data, n, 4096, 1, C.byref(st))
         F.dropin_feed(x.ctypes.data, n, 4096, 3, C.byref(st))
