@@ -194,7 +194,7 @@ struct FxBlockHdr {                      // device memory, zeroed at submit; mir
     uint32_t pll_base[FX_PLL_CLASSES + 1];   // first list slot of each class (multiples of 64: a wave never mixes classes)
     uint64_t sym_total, byte_total, dw_total, out_total;
     uint32_t hops, hops_cheap, repairs, verify_hops, verify_failures, walk_jobs_run;
-    uint32_t vb_ticket;                  // fx_vbfinish_kernel: waves done (the last one publishes n_vb_fallback to the host's copy)
+    uint32_t vb_ticket;                  // host mirror only: fx_vbfinish_kernel handed frames back to the wave-per-frame decoder (n_vb_fallback on the device says how many)
     uint32_t done;                       // host mirror only: written last
     uint32_t stamp[8];
 };

@@ -64,7 +64,8 @@ extern "C" unsigned fx_plan_ws_words(void);
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
                                       const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, const FxTables *T);
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
-                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed);
+                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed,
+                                        int with_fix);
 extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
                                          uint8_t *bufA, uint8_t *bufB, unsigned long long *dwv, const uint8_t *vec_arena, const uint32_t *vb_st, uint32_t *fb_list, uint32_t list_cap,
                                          uint8_t *out, FxOutRec *recs, FxBlockHdr *hdr_host);
@@ -212,6 +213,7 @@ struct fxrx_ctx_s {
     int timing_level = -1;               // stage events per block: -1 auto (all stages one block at a time, none with blocks in flight) | 0 none | 1 the PLL only | 2 all stages
     hipEvent_t ref_event = nullptr; double ref_host_ms = 0.0;   // fxrx_debug_block_times: a common origin of GPU and host clocks
     int debug_stop_after = 0;            // FXRX_DEBUG_STOP_AFTER (tools/dev/dev_stage_cost.py): 4 plan | 5 matched filter | 6 PLL -- the chain ends there, no results
+    uint64_t vbfix_hint = 0;             // the last collected block's batch Viterbi path ran blocks again / handed frames back: the hand-over check is launched with the next one
     uint64_t fb_hint = 0;                // frames the last collected block's batch Viterbi path handed back (sizes the fallback launch; 0: none enqueued)
     uint32_t walk_per_cu = 2;            // walker workgroups resident per CU (FXRX_WALK_PER_CU; follows the kernel's register budget)
     hipStream_t st_chain = nullptr;      // highest priority: the state-dependent stretch of continuing blocks (true walkers, their verification, chain kernel)
@@ -553,7 +555,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         sl.d_pjobs.reserve(chain_slots) || sl.h_recs.reserve(chain_slots) || sl.d_mf_job.reserve(sl.mf_cap) || sl.d_mf_c0.reserve(sl.mf_cap) ||
         sl.d_pll_list.reserve(list_cap) || sl.d_dec_list.reserve(4 * (size_t)list_cap)) return FXRX_ERR_HIP;
     if (!detect && (sl.d_symraw.reserve(sl.sym_cap) || sl.d_hard.reserve(sl.sym_cap + 64) ||
-                    sl.d_bufA.reserve(sl.byte_cap) || sl.d_bufB.reserve(sl.byte_cap) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
+                    sl.d_bufA.reserve(sl.byte_cap + 256) || sl.d_bufB.reserve(sl.byte_cap + 256) || sl.d_dw.reserve(sl.dw_cap) || sl.h_out.reserve(sl.out_cap))) return FXRX_ERR_HIP;
     if (!detect && c->cfg.want_framesyms && sl.h_framesyms.reserve(sl.sym_cap)) return FXRX_ERR_HIP;
     if (!sl.d_plan_ws.p) {
         if (sl.d_plan_ws.reserve(fx_plan_ws_words())) return FXRX_ERR_HIP;
@@ -611,8 +613,11 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[2], cst));
     // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
     // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
+    static const bool dbg_no_order = std::getenv("FXRX_DEBUG_NO_ORDER") != nullptr;      // experiment only: unsafe for continuing streams
+    if (!dbg_no_order) {
     if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
     if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(cst, c->carry_reader[(b + 1) % 3], 0));
+    }
     return enqueue_back(c, sl, kChainFast, cst);
 }
 
@@ -710,7 +715,7 @@ static int enqueue_back(fxrx_ctx_s *c, Slot &sl, int chain_mode, hipStream_t cha
             sl.vb_items_launched = c->first_block ? sl.vb_cap : (unsigned)std::min<uint64_t>(sl.vb_cap, c->vb_items_hint + c->vb_items_hint / 2 + 1024);
             HIP_OK(fx_launch_vbpre(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
             HIP_OK(fx_launch_vbitems(0, sl.vb_items_launched, st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p,
-                                     sl.d_vb_st.p, c->vb_debug, vb_packed));
+                                     sl.d_vb_st.p, c->vb_debug, vb_packed, (c->first_block || c->vbfix_hint || c->vb_debug) ? 1 : 0));
             HIP_OK(fx_launch_vbfinish(0, sl.vb_pre_launched, st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
                                       sl.d_vb_vec.p, sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p, sl.h_hdr.p));
             // frames whose hand-overs could not be verified (a block that ran again and ended differently): the wave-per-frame decoder,
@@ -925,6 +930,11 @@ static int repair_and_replay(fxrx_ctx_s *c, Slot &sl)
 // Reed-Solomon frames turning up unannounced): decode them now, on the block's stream, and wait
 static int finish_decode(fxrx_ctx_s *c, Slot &sl)
 {
+    if (sl.vb_blk && sl.h_hdr.p->vb_ticket) {          // frames were handed back: how many (the block is done: a plain copy)
+        uint32_t n_fb = 0;
+        HIP_OK(hipMemcpy(&n_fb, &(sl.d_hdr.p + 1)->n_vb_fallback, sizeof n_fb, hipMemcpyDeviceToHost));
+        sl.h_hdr.p->n_vb_fallback = n_fb; sl.h_hdr.p->vb_ticket = 0;
+    }
     const FxBlockHdr &h = *sl.h_hdr.p;
     const bool more_plain = h.n_dec_plain > sl.dec_launched, more_rs = h.n_dec_rs > 0 && sl.rs_launched == 0;   // (the Reed-Solomon instance strides: any launch covers all)
     const bool more_batch = h.n_dec_batch > sl.vb_pre_launched || h.n_vb_items > sl.vb_items_launched;
@@ -946,14 +956,14 @@ static int finish_decode(fxrx_ctx_s *c, Slot &sl)
     if (more_batch) {       // (all parts again, for all of the path's frames: they are idempotent -- but for the fallback list, which starts over)
         HIP_OK(hipMemsetAsync(&hdr_pay->n_vb_fallback, 0, sizeof(uint32_t), sl.st));
         HIP_OK(fx_launch_vbpre(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p, c->d_tables));
-        HIP_OK(fx_launch_vbitems(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p, sl.d_vb_st.p, c->vb_debug, 1));
-        HIP_OK(hipMemsetAsync(&hdr_pay->vb_ticket, 0, sizeof(uint32_t), sl.st));
+        HIP_OK(fx_launch_vbitems(0, h.n_vb_items, sl.st, sl.d_pjobs.p, sl.d_vb_items.p, sl.vb_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p, sl.d_vb_vec.p, sl.d_vb_st.p, c->vb_debug, 1, 1));
         HIP_OK(fx_launch_vbfinish(0, h.n_dec_batch, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 2 * (size_t)list_cap, hdr_pay, sl.d_bufA.p, sl.d_bufB.p, sl.d_vb_dw.p,
                                   sl.d_vb_vec.p, sl.d_vb_st.p, sl.d_dec_list.p + 3 * (size_t)list_cap, list_cap, sl.h_out.p, sl.h_recs.p, sl.h_hdr.p));
         HIP_OK(fx_launch_paydec(0, 0, 0, kFallbackWaves, 1u, sl.st, sl.d_pjobs.p, sl.d_dec_list.p + 3 * (size_t)list_cap, hdr_pay, sl.d_hard.p, sl.d_bufA.p, sl.d_bufB.p,
                                 sl.d_soft.p, sl.d_dw.p, sl.h_out.p, sl.h_recs.p, pres, c->d_tables, sl.h_hdr.p));
         sl.vb_pre_launched = h.n_dec_batch; sl.vb_items_launched = h.n_vb_items; sl.fb_launched = kFallbackWaves;
         HIP_OK(hipStreamSynchronize(sl.st));
+        { uint32_t nfb = 0; HIP_OK(hipMemcpy(&nfb, &hdr_pay->n_vb_fallback, sizeof nfb, hipMemcpyDeviceToHost)); sl.h_hdr.p->n_vb_fallback = nfb; sl.h_hdr.p->vb_ticket = 0; }
     }
     const uint32_t n_fb = *(volatile const uint32_t *)&sl.h_hdr.p->n_vb_fallback;
     if (sl.vb_blk && n_fb > sl.fb_launched) {
@@ -1086,7 +1096,7 @@ static int collect_block(fxrx_ctx_s *c)
             S.carry_bound = std::min<int64_t>(S.carry_bound, std::min<int64_t>(S.carry_cap, hs[s].carry_len + (S.total - end_total)));
     }
     c->frames_hint = h.n_frames; c->plain_hint = h.n_dec_plain; c->batch_hint = h.n_dec_batch; c->vb_items_hint = h.n_vb_items;
-    c->fb_hint = h.n_vb_fallback; c->mf_items_hint = h.n_mfblk; c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
+    c->fb_hint = h.n_vb_fallback; c->vbfix_hint = h.n_vb_fallback + vb_rep; c->mf_items_hint = h.n_mfblk; c->vb_want_hint = h.vb_want; c->vb_steps_hint = (uint64_t)h.vb_want * (h.vb_blk ? h.vb_blk : 1u); c->first_block = false;
     c->rs_hint = h.n_dec_rs ? h.n_dec_rs : c->rs_hint - std::min<uint64_t>(c->rs_hint, std::max<uint64_t>(1, c->rs_hint / 8));   // (fades out, to zero, over a few dozen blocks without such frames)
     if (h.verify_hops) c->verify_per = (uint32_t)std::min<uint64_t>(16, std::max<uint64_t>(1, ((uint64_t)h.verify_hops + 4ull * c->n_cus - 1) / (4ull * c->n_cus)));
     fxrx_timing &t = sl.timing;

@@ -363,7 +363,14 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
         if (!in_handoff) nh = (int)min((int64_t)nh, (stop - pos + FX_HOP - 1) / FX_HOP);
         const int64_t fl0 = fresh ? max(floor_, pos) : floor_;        // (a freshly reset detector's overlap half is zeros)
         __syncthreads();
-        for (int i = tid; i < (nh + 1) * FX_HOP; i += NT) L.cw[i] = xv(xs, pos - FX_HOP + i, i < FX_HOP ? fl0 : floor_);
+        {
+            constexpr int NLD = ((WW + 1) * FX_HOP + NT - 1) / NT;
+            float2 ld[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; k++) { const int i = tid + NT * k; ld[k] = i < (nh + 1) * FX_HOP ? xv(xs, pos - FX_HOP + i, i < FX_HOP ? fl0 : floor_) : make_float2(0.0f, 0.0f); }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) { const int i = tid + NT * k; if (i < (nh + 1) * FX_HOP) L.cw[i] = ld[k]; }
+        }
         __syncthreads();
         if (wave < nh) {
             uint32_t bidx; int boff; float peak;
@@ -619,7 +626,14 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         if ((!locked || may_skip) && MODE == FX_MODE_FLEXRX && exact_left == 0 && pos + WALK_WAVES * FX_HOP <= n &&
             (in_handoff || pos + (WALK_WAVES - 1) * FX_HOP < stop)) {
             __syncthreads();
-            for (int i = tid; i < (WALK_WAVES + 1) * FX_HOP; i += WALK_THREADS) L.cw[i] = xv(xs, pos - FX_HOP + i, floor_);
+            {   // (all of a thread's loads in flight at once: a rolled load / store loop pays the memory latency once per pass)
+                constexpr int NLD = ((WALK_WAVES + 1) * FX_HOP + WALK_THREADS - 1) / WALK_THREADS;
+                float2 ld[NLD];
+#pragma unroll
+                for (int k = 0; k < NLD; k++) { const int i = tid + WALK_THREADS * k; ld[k] = i < (WALK_WAVES + 1) * FX_HOP ? xv(xs, pos - FX_HOP + i, floor_) : make_float2(0.0f, 0.0f); }
+#pragma unroll
+                for (int k = 0; k < NLD; k++) { const int i = tid + WALK_THREADS * k; if (i < (WALK_WAVES + 1) * FX_HOP) L.cw[i] = ld[k]; }
+            }
             __syncthreads();
             hops_cheap += WALK_WAVES;
             {
@@ -800,7 +814,14 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
 
         // ------------------------------------------------------------ ALIGN on x[a0, a0+512)
         __syncthreads();
-        for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.win[i] = xv(xs, a0 + i, floor_);
+        {
+            constexpr int NLD = (FX_NFFT + WALK_THREADS - 1) / WALK_THREADS;
+            float2 ld[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; k++) { const int i = tid + WALK_THREADS * k; ld[k] = i < FX_NFFT ? xv(xs, a0 + i, floor_) : make_float2(0.0f, 0.0f); }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) { const int i = tid + WALK_THREADS * k; if (i < FX_NFFT) L.win[i] = ld[k]; }
+        }
         __syncthreads();
         if (wave == 0) {
             float2 a[8];
@@ -920,8 +941,14 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
         constexpr int dly = EQ ? FX_EQ_DELAY : 0;                      // the equaliser moves every symbol instant 3 symbols later
         const int nh = (int)sym_sample(FX_SYM0_PAY + dly - 1, fr.mfc0);  // sample of the last header symbol
         if (a0 + nh + 1 > n) { exit_code = FX_EXIT_NEED_DATA; break; }
-        for (int m = tid; m <= nh; m += WALK_THREADS)
-            L.v[m] = derot(xv(xs, a0 + m, floor_), fr.mix_th + mix_dl * (uint32_t)m, sc);
+        {
+            constexpr int NLD = (640 + WALK_THREADS - 1) / WALK_THREADS;        // (nh < 640: the preamble + header span)
+            float2 ld[NLD];
+#pragma unroll
+            for (int k = 0; k < NLD; k++) { const int m = tid + WALK_THREADS * k; ld[k] = m <= nh ? xv(xs, a0 + m, floor_) : make_float2(0.0f, 0.0f); }
+#pragma unroll
+            for (int k = 0; k < NLD; k++) { const int m = tid + WALK_THREADS * k; if (m <= nh) L.v[m] = derot(ld[k], fr.mix_th + mix_dl * (uint32_t)m, sc); }
+        }
         if (tid < FX_MF_TAPS) L.taps[tid] = T->proto[fr.pfb + FX_NPFB * tid];
         __syncthreads();
         if (!EQ) {
@@ -3118,7 +3145,7 @@ static_assert(FX_VB_WARM <= 128, "trellis blocks are at least 128 steps: a block
 // little redundancy per step and take longest (at marginal SNR a 96-step warm-up left every sixth of their blocks to be run again)
 __device__ __forceinline__ uint32_t vb_warm(int p) { return p == 1 ? 64u : (p >= 5 ? 128u : (uint32_t)FX_VB_WARM); }
 #ifndef FX_VB_TWARM
-#define FX_VB_TWARM 128           // traceback warm-up: steps of the next block traced from state 0 to guess the block's end state
+#define FX_VB_TWARM 64            // traceback warm-up: steps of the next block traced from state 0 to guess the block's end state
 #endif
 
 // ---- the forward pass proper: TWO trellis blocks per lane, their doubled metrics side by side in the 16-bit halves of a
@@ -3229,7 +3256,23 @@ struct VbHalf {                       // one of a lane's two work items
 // Forward pass of a lane's two trellis blocks (same puncturing code p): vb_warm(p) steps of warm-up from all-equal
 // metrics (a frame's first block idles instead and starts from the encoder's state), then blk region steps whose decisions
 // go to the blocks' slabs; start and end metric differences to the blocks' vector slots.
-__device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A, const VbHalf &B)
+// Coded bits reach the lanes through LDS: every 128 steps a lane fetches the 64 bytes (16-byte aligned) that hold its block's next
+// <= 256 coded bits and parks them in its own 17-dword row (odd stride: no bank conflicts); the 64-bit window the steps eat from is
+// refilled from there every 16 steps.  (Refilling it straight from global memory -- two dwords per lane, 64 lanes 36 to 100 bytes
+// apart, back in the same cache lines sixteen steps later -- cost 35 x the coded bits in HBM fetches on config 4: the lines did not
+// survive in the L2 between visits.)
+#define VB_ROW 17
+__device__ __forceinline__ void vb_stage(const uint8_t *enc, uint32_t nb, bool on, uint32_t *row, uint32_t &lbase)
+{
+    const uint32_t o = (nb >> 3) & ~15u;
+    const uint4 *src = reinterpret_cast<const uint4 *>(enc + o);
+    uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0;
+    if (on) { q0 = src[0]; q1 = src[1]; q2 = src[2]; q3 = src[3]; }
+    row[0] = q0.x; row[1] = q0.y; row[2] = q0.z; row[3] = q0.w; row[4] = q1.x; row[5] = q1.y; row[6] = q1.z; row[7] = q1.w;
+    row[8] = q2.x; row[9] = q2.y; row[10] = q2.z; row[11] = q2.w; row[12] = q3.x; row[13] = q3.y; row[14] = q3.z; row[15] = q3.w;
+    lbase = o << 3;
+}
+__device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A, const VbHalf &B, uint32_t *lds)
 {
     uint32_t Q[64], N[64];
 #pragma unroll
@@ -3243,7 +3286,8 @@ __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A
         sa.col = tsa % up; sa.nb = (p == 1) ? 2u * tsa : tsa + (tsa + up - 1u) / up; sa.w0 = sa.w1 = sa.wbase = 0;
         sb.col = tsb % up; sb.nb = (p == 1) ? 2u * tsb : tsb + (tsb + up - 1u) / up; sb.w0 = sb.w1 = sb.wbase = 0;
     }
-    const uint32_t *ea = reinterpret_cast<const uint32_t *>(A.enc), *eb = reinterpret_cast<const uint32_t *>(B.enc);   // (byte_off is a multiple of 16)
+    uint32_t *rowa = lds + (threadIdx.x & 63) * VB_ROW, *rowb = lds + (64 + (threadIdx.x & 63)) * VB_ROW;
+    uint32_t la = 0, lb = 0;
     const uint32_t nsteps = warm + blk;
     for (uint32_t u = 0; u < nsteps; u += 2) {
         if (u == warm) {
@@ -3258,11 +3302,11 @@ __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A
                 for (int i = 0; i < 64; i++) Q[i] = (Q[i] & 0x0000FFFFu) | (i ? 1024u << 16 : 0u);
             } else if (B.on) vb2_save_vec(Q, 1, B.vec);
         }
-        if ((u & 15u) == 0u) {                                             // refill the 64-bit windows of coded bits
-            const uint32_t ia = sa.nb >> 5, ib = sb.nb >> 5;
-            const uint32_t x0 = A.on ? ea[ia] : 0u, x1 = A.on ? ea[ia + 1] : 0u, y0 = B.on ? eb[ib] : 0u, y1 = B.on ? eb[ib + 1] : 0u;
-            sa.w0 = __builtin_bswap32(x0); sa.w1 = __builtin_bswap32(x1); sa.wbase = ia << 5;
-            sb.w0 = __builtin_bswap32(y0); sb.w1 = __builtin_bswap32(y1); sb.wbase = ib << 5;
+        if ((u & 127u) == 0u) { vb_stage(A.enc, sa.nb, A.on, rowa, la); vb_stage(B.enc, sb.nb, B.on, rowb, lb); }
+        if ((u & 15u) == 0u) {                                             // refill the 64-bit windows of coded bits (own row: no barrier needed)
+            const uint32_t ia = (sa.nb - la) >> 5, ib = (sb.nb - lb) >> 5;
+            sa.w0 = __builtin_bswap32(rowa[ia]); sa.w1 = __builtin_bswap32(rowa[ia + 1]); sa.wbase = la + (ia << 5);
+            sb.w0 = __builtin_bswap32(rowb[ib]); sb.w1 = __builtin_bswap32(rowb[ib + 1]); sb.wbase = lb + (ib << 5);
         }
         const bool in_reg = u >= warm;
         const bool run_a = in_reg || !A.first, run_b = in_reg || !B.first;     // (a block that idles keeps its stream position)
@@ -3271,10 +3315,15 @@ __device__ __forceinline__ void vb2_forward(int p, uint32_t blk, const VbHalf &A
         vb2_step(N, Q, pa, pb, up, sa, sb, run_a, run_b, a1, b1);
         // (regions are an even number of steps long within the slab: step ur + 1 is inside it whenever ur is)
         const uint32_t ur = u - warm;
-        // (decision words stream through -- written once, read once by the traceback --: non-temporal, so that they do not push the
-        // coded bits, which every lane comes back to sixteen steps later, out of the L2)
-        if (A.on && in_reg && A.t_reg + ur < A.t1) { __builtin_nontemporal_store(a0, A.dwl + (size_t)ur * 64u); __builtin_nontemporal_store(a1, A.dwl + (size_t)(ur + 1u) * 64u); }
-        if (B.on && in_reg && B.t_reg + ur < B.t1) { __builtin_nontemporal_store(b0, B.dwl + (size_t)ur * 64u); __builtin_nontemporal_store(b1, B.dwl + (size_t)(ur + 1u) * 64u); }
+        // decision words stream through -- written once, read once by the traceback: non-temporal, so that they do not flood the L2 --
+        // except the first FX_VB_TWARM steps of a block, which this lane reads back at the end for the traceback's guess
+        if (in_reg && ur < (uint32_t)FX_VB_TWARM) {
+            if (A.on && A.t_reg + ur < A.t1) { A.dwl[(size_t)ur * 64u] = a0; A.dwl[(size_t)(ur + 1u) * 64u] = a1; }
+            if (B.on && B.t_reg + ur < B.t1) { B.dwl[(size_t)ur * 64u] = b0; B.dwl[(size_t)(ur + 1u) * 64u] = b1; }
+        } else {
+            if (A.on && in_reg && A.t_reg + ur < A.t1) { __builtin_nontemporal_store(a0, A.dwl + (size_t)ur * 64u); __builtin_nontemporal_store(a1, A.dwl + (size_t)(ur + 1u) * 64u); }
+            if (B.on && in_reg && B.t_reg + ur < B.t1) { __builtin_nontemporal_store(b0, B.dwl + (size_t)ur * 64u); __builtin_nontemporal_store(b1, B.dwl + (size_t)(ur + 1u) * 64u); }
+        }
     }
     if (A.on) vb2_save_vec(Q, 0, A.vec + 64);
     if (B.on) vb2_save_vec(Q, 1, B.vec + 64);
@@ -3295,7 +3344,7 @@ __device__ __forceinline__ VbItem vb_item(const FxPayJob *jobs, const uint32_t *
     return it;
 }
 
-extern "C" __global__ __launch_bounds__(64)
+extern "C" __global__ __launch_bounds__(64, 3)
 void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
                      unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st)
 {
@@ -3319,7 +3368,8 @@ void fx_vbfwd_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t it
     A.dwl = vb_slab(dwv, slot_a, blk); A.vec = vec_arena + (size_t)slot_a * 128u;
     B.enc = bufB + jb.byte_off; B.on = ib.on; B.first = !ib.on || ib.b == 0; B.t_reg = B.first && !ib.on ? 0u : ib.t_reg; B.t1 = ib.t1;
     B.dwl = vb_slab(dwv, ib.on ? slot_b : slot_a, blk); B.vec = vec_arena + (size_t)(ib.on ? slot_b : slot_a) * 128u;
-    vb2_forward(p, blk, A, B);
+    __shared__ uint32_t rows[128 * VB_ROW];
+    vb2_forward(p, blk, A, B, rows);
     if (ia.on) vb_st[slot_a] = vb_make_guess(A.dwl, ia.t1 - ia.t_reg);
     if (ib.on) vb_st[slot_b] = vb_make_guess(B.dwl, ib.t1 - ib.t_reg);
 }
@@ -3356,11 +3406,32 @@ __device__ __forceinline__ bool vb_same64(const uint8_t *a, const uint8_t *b)
     return same;
 }
 
-// ---- hand-over check (first thing fx_vbtrace_kernel does): a block whose warm-up did not arrive at the true metric differences
-// -- its start record differs from the end record of the block before it -- runs again from them, by the lane that is about to
-// trace it back.  No ordering between lanes is assumed: the block before may itself be running again at that moment and end
-// differently.  Results never rest on that: fx_vbfinish_kernel compares, for every block of a frame, the FINAL start record with
-// the FINAL end record of its predecessor and hands the frame to the wave-per-frame decoder if any pair differs.
+// ---- hand-over check: a block whose warm-up did not arrive at the true metric differences -- its start record differs from the end
+// record of the block before it -- runs again from them (same lanes as the forward pass; a wave without such a block leaves at
+// once).  An optimisation only, launched while blocks keep needing it (fx_host.cpp): results never rest on it -- fx_vbfinish_kernel
+// compares, for every block of a frame, the FINAL start record with the FINAL end record of its predecessor and hands the frame to
+// the wave-per-frame decoder if any pair differs (a block that ran again here and ended differently leaves such a pair behind it).
+extern "C" __global__ __launch_bounds__(64)
+void fx_vbfix_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, const uint8_t *bufB,
+                     unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+{
+    const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
+    const uint32_t it0 = first_item + blockIdx.x * 64u;
+    if (it0 >= nitems) return;
+    const uint32_t slot = it0 + threadIdx.x;
+    const VbItem it = vb_item(jobs, vb_items, item_cap, slot, blk);
+    uint8_t *vec = vec_arena + (size_t)slot * 128u;
+    // (dbg bit 1, tests only: every other failing block is left as it is, for the fallback path to be exercised)
+    const bool bad = it.on && it.b > 0 && !vb_same64(vec, vec - 64) && !((dbg & 2u) && (slot & 1u));
+    const unsigned long long fails = __ballot(bad);
+    if (!fails) return;
+    const FxPayJob &job = jobs[it.g];
+    const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)fails) - 1, 64));
+    unsigned long long *dwl = vb_slab(dwv, slot, blk);
+    vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, 2, bad ? vec - 64 : vec, dwl, vec, vec + 64, blk, 0u, bad);
+    if (bad) vb_st[slot] = VB_ST_REP | vb_make_guess(dwl, it.t1 - it.t_reg);       // (fx_vbfinish_kernel counts these; the guess: from the new decisions)
+}
+
 // sixteen traceback steps u0 + 15 .. u0 of one lane (those below lim only): the words first, then the chain through them
 __device__ __forceinline__ void vb_trace16(const unsigned long long *dwl, uint32_t u0, uint32_t lim, unsigned &st, uint32_t &bits16)
 {
@@ -3405,8 +3476,8 @@ __device__ __forceinline__ unsigned vb_trace_chunk(const unsigned long long *dwl
 // next block from state 0 (the survivors of all states merge within a few constraint lengths) and starts from where that
 // arrives.  fx_vbfinish_kernel checks that guess against the state the next block's traceback really arrived at.
 extern "C" __global__ __launch_bounds__(64)
-void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, uint8_t *bufA, const uint8_t *bufB,
-                       unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg)
+void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap, const FxBlockHdr *hdr, uint32_t first_item, uint8_t *bufA,
+                       unsigned long long *dwv, uint32_t *vb_st, uint32_t dbg)
 {
     const uint32_t nitems = hdr->n_vb_items, blk = hdr->vb_blk;
     const uint32_t it0 = first_item + blockIdx.x * 64u;
@@ -3418,17 +3489,8 @@ void fx_vbtrace_kernel(const FxPayJob *jobs, const uint32_t *vb_items, uint32_t 
     const uint32_t len = it.on ? it.t1 - it.t_reg : 0u;
     uint32_t old = it.on ? vb_st[slot] : 0u;
     uint32_t flags = 0u;
-    uint8_t *vec = vec_arena + (size_t)slot * 128u;
-    unsigned long long *dwl = vb_slab(dwv, slot, blk);
-    {   // hand-over check (dbg bit 1, tests only: every other failing block is left as it is, for the fallback path to be exercised)
-        const bool bad = it.on && it.b > 0 && !vb_same64(vec, vec - 64) && !((dbg & 2u) && (slot & 1u));
-        const unsigned long long fails = __ballot(bad);
-        if (fails) {
-            const int p = conv_p((unsigned)__shfl((int)job.fec0, __ffsll((long long)fails) - 1, 64));
-            vb_forward(bufB + job.byte_off, p, it.t_reg, it.t1, 2, bad ? vec - 64 : vec, dwl, vec, vec + 64, blk, 0u, bad);
-            if (bad) { flags |= VB_ST_REP; old = (old & ~0x3F000000u) | vb_make_guess(dwl, len); }      // (fx_vbfinish_kernel counts these; the guess: from the new decisions)
-        }
-    }
+    const unsigned long long *dwl = vb_slab(dwv, slot, blk);
+    flags = old & VB_ST_REP;
     // the end state: 0 behind the flushed tail; elsewhere the guess the next block's forward pass left (its first FX_VB_TWARM
     // steps traced back from state 0)
     const bool has_next = it.on && it.b + 1u < it.nblk;
@@ -3555,19 +3617,6 @@ void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHd
     const uint32_t ji = first_wave + blockIdx.x;
     if (ji >= njobs) return;
     const int lane = threadIdx.x & 63;
-    // the wave that finishes last tells the host how many frames were handed back (fxrx_collect decodes them the other way if the
-    // chain did not): waves of this launch that have a frame = min(njobs, first_wave + grid) - first_wave
-    auto done = [&]() {
-        __threadfence();
-        if (lane == 0) {
-            const uint32_t mine = min(njobs, first_wave + gridDim.x) - first_wave;
-            if (atomicAdd(&hdr->vb_ticket, 1u) == mine - 1u) {
-                __threadfence();
-                hdr_host->n_vb_fallback = __hip_atomic_load(&hdr->n_vb_fallback, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hdr->vb_ticket = 0u;
-            }
-        }
-    };
     const uint32_t jf = job_idx[ji];
     FxPayJob job = jobs[jf];
     job.k = __builtin_amdgcn_readfirstlane(job.k); job.pay_len = __builtin_amdgcn_readfirstlane(job.pay_len);
@@ -3580,13 +3629,14 @@ void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHd
         const uint32_t b = base + (uint32_t)lane;
         const uint32_t v = b < nblk ? vb_st[at + b] : 0u, vn = b + 1u < nblk ? vb_st[at + b + 1u] : 0u;
         // every hand-over, on the records as they stand now: block b started from what block b - 1 ended with
-        if (b > 0 && b < nblk) { const uint8_t *vec = vec_arena + (size_t)(at + b) * 128u; bad = bad || !vb_same64(vec, vec - 64); }
+        if (b > 0 && b < nblk) { const uint8_t *vec = vec_arena + (size_t)(at + b) * 128u; const bool same = vb_same64(vec, vec - 64); bad = bad || !same; }
         rep += (uint32_t)__popcll(__ballot((v & VB_ST_REP) != 0u));
         mism = mism || (b + 1u < nblk && (v & 0xffu) != ((vn >> 8) & 0xffu));
     }
     if (__any(bad)) {                                                       // an unverified hand-over: the frame is decoded the other way
-        if (lane == 0) { const uint32_t s = atomicAdd(&hdr->n_vb_fallback, 1u); if (s < list_cap) fb_list[s] = jf; }
-        done();
+        // (the host's copy only learns THAT frames were handed back -- a plain store, whoever gets there --; fxrx_collect then fetches the
+        // count if the fallback launch of the chain, sized from the last block, may not have covered it)
+        if (lane == 0) { const uint32_t s = atomicAdd(&hdr->n_vb_fallback, 1u); if (s < list_cap) fb_list[s] = jf; hdr_host->vb_ticket = 1u; }
         return;
     }
     if (__any(mism)) {                                                      // a wrong end-state guess: from the last block downwards
@@ -3600,7 +3650,6 @@ void fx_vbfinish_kernel(const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHd
     (void)Tn;
     __threadfence_block(); __builtin_amdgcn_wave_barrier();
     dec_tail(job, jf, A, lane, out, recs, rep << 8);
-    done();
 }
 
 extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, const FxBlockHdr *hdr,
@@ -3610,15 +3659,17 @@ extern "C" hipError_t fx_launch_vbpre(unsigned first_wave, unsigned n_waves, hip
     hipLaunchKernelGGL(fx_vbpre_kernel, dim3(n_waves), dim3(DEC_THREADS), 0, st, jobs, job_idx, hdr, first_wave, hard, bufA, bufB, T);
     return hipGetLastError();
 }
-// forward pass and traceback (with the hand-over check in front): the two lane-per-work-item kernels, over the same item slots
+// forward pass, [hand-over check,] traceback: the lane-per-work-item kernels, over the same item slots
 extern "C" hipError_t fx_launch_vbitems(unsigned first_item, unsigned n_items, hipStream_t st, const FxPayJob *jobs, const uint32_t *vb_items, uint32_t item_cap,
-                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed)
+                                        const FxBlockHdr *hdr, uint8_t *bufA, const uint8_t *bufB, unsigned long long *dwv, uint8_t *vec_arena, uint32_t *vb_st, uint32_t dbg, int packed,
+                                        int with_fix)
 {
     if (n_items == 0) return hipSuccess;
     const dim3 grid((n_items + 63) / 64), block(64);
     if (!packed) hipLaunchKernelGGL(fx_vbfwd1_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
     else hipLaunchKernelGGL(fx_vbfwd_kernel, dim3((n_items + 127) / 128), block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st);
-    hipLaunchKernelGGL(fx_vbtrace_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufA, bufB, dwv, vec_arena, vb_st, dbg);
+    if (with_fix) hipLaunchKernelGGL(fx_vbfix_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufB, dwv, vec_arena, vb_st, dbg);
+    hipLaunchKernelGGL(fx_vbtrace_kernel, grid, block, 0, st, jobs, vb_items, item_cap, hdr, first_item, bufA, dwv, vb_st, dbg);
     return hipGetLastError();
 }
 extern "C" hipError_t fx_launch_vbfinish(unsigned first_wave, unsigned n_waves, hipStream_t st, const FxPayJob *jobs, const uint32_t *job_idx, FxBlockHdr *hdr,
