@@ -350,6 +350,22 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
     const float2 *sc = T->sc;
     const bool lo = tid < HALF;
     float2 *win = L.cw, *X = L.cw + FX_NFFT, *P = L.cw + 2 * FX_NFFT; float *m2 = reinterpret_cast<float *>(L.scr[1]);
+    // Re-sync (walks of a repair round only): this segment was walked before, speculatively, and is walked again because the true
+    // chain enters it in a state its list did not anticipate.  From the first detection the two walks have in common on, the old
+    // list IS what the sequential machine produces (same rule as a splice: a locked detection at the same start and CFO bin, no
+    // zero-floor in the way), so the new walk only has to bridge the gap: it writes its frames into the upper half of the segment's
+    // table, looks every detection up in the old list below, and on the first hit appends the old list's remainder, moves the
+    // whole to the front and takes over the old walk's result.  A segment re-walk costs a frame or two instead of the whole segment.
+    uint32_t fbase = 0, n_old = 0; FxWalkResult old_res;
+    bool resync = false;
+    if constexpr (EXT) {
+        if (job.pad_ && all_results) {
+            old_res = all_results[job_index];
+            n_old = old_res.n_frames;
+            if (n_old > 0 && n_old <= job.max_frames / 2 && old_res.exit_code != FX_EXIT_INVALID) { resync = true; fbase = job.max_frames / 2; }
+        }
+    }
+    const uint32_t fcap = resync ? job.max_frames - fbase : job.max_frames;
 
     for (;;) {
         pos = uniform64(pos); floor_ = uniform64(floor_);
@@ -408,7 +424,57 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
                 }
                 if (!extend) { has_handoff = 1; ho_start = a0; ho_off = boff; ho_rxy = peak; ho_pos = hp; ho_clear = floor_ <= a0 ? 1u : 0u; exit_code = FX_EXIT_STOP; pos = hp; fresh = fresh && h == 0; leave = true; break; }
             }
-            if (nfr >= job.max_frames) { exit_code = FX_EXIT_TABLE_FULL; pos = hp; fresh = fresh && h == 0; leave = true; break; }
+            if constexpr (EXT) {
+                if (resync && !in_handoff && floor_ <= a0) {
+                    const FxFrame *FO = frames + job.frame_base;
+                    __syncthreads();
+                    if (tid == 0) L.u[15] = 0xFFFFFFFFu;
+                    __syncthreads();
+                    for (uint32_t i = tid; i < n_old; i += NT) {
+                        const uint32_t fl = FO[i].flags;
+                        if ((fl & FX_FLAG_EXACT) && (fl & FX_FLAG_FLOOR_CLEAR) && FO[i].start == a0 && FO[i].offset == boff) atomicMin(&L.u[15], i);
+                    }
+                    __syncthreads();
+                    const uint32_t hit = L.u[15];
+                    if (hit != 0xFFFFFFFFu) {
+                        const uint32_t q = hit, n_tail = n_old - q;
+                        if (nfr + n_tail <= fcap) {
+                            FxFrame *FW = frames + job.frame_base;
+                            // old[q, n_old) behind the new frames, then everything to the front (the two ranges may overlap: staged moves, a frame per thread and pass)
+                            for (uint32_t i0 = 0; i0 < n_tail; i0 += NT) {
+                                const uint32_t i = i0 + tid; FxFrame t;
+                                if (i < n_tail) t = FW[q + i];
+                                __syncthreads();
+                                if (i < n_tail) FW[fbase + nfr + i] = t;
+                                __syncthreads();
+                            }
+                            __threadfence(); __syncthreads();
+                            const uint32_t n_all = nfr + n_tail;
+                            for (uint32_t i0 = 0; i0 < n_all; i0 += NT) {
+                                const uint32_t i = i0 + tid; FxFrame t;
+                                if (i < n_all) t = FW[fbase + i];
+                                __syncthreads();
+                                if (i < n_all) {
+                                    if (i == nfr) {                     // the frame both walks found: its seek is this walk's (exact), its coarse peak the true chain's
+                                        t.rxy = peak; t.seek_pos = span_pos; t.seek_floor = span_floor; t.det_pos = hp;
+                                        t.flags = (t.flags & ~(uint32_t)(FX_FLAG_SPAN_BAD | FX_FLAG_SEEK_FRESH)) | span_flags;
+                                    }
+                                    FW[i] = t;
+                                }
+                                __syncthreads();
+                            }
+                            if (tid == 0) {
+                                FxWalkResult r = old_res;
+                                r.n_frames = n_all; r.hops = hops;
+                                *result = r;
+                                atomicAdd(&hdr->hops, hops); atomicAdd(&hdr->walk_jobs_run, 1u);
+                            }
+                            return;
+                        }
+                    }
+                }
+            }
+            if (nfr >= fcap) { exit_code = FX_EXIT_TABLE_FULL; pos = hp; fresh = fresh && h == 0; leave = true; break; }
             if (a0 + FX_NFFT > n) { exit_code = FX_EXIT_NEED_DATA; pos = hp; fresh = fresh && h == 0; leave = true; break; }
             // Speculative walker not yet locked: a weak peak may be a false alarm the sequential chain never sees (its hop grid
             // differs).  Ignore it and keep the grid; lock on a strong one.
@@ -501,7 +567,7 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
             for (int j = 0; j < FX_HDR_DEC; j++) fr.header[j] = 0;
             locked = true;
             fr.next = a0 + FX_NFFT;                                       // back to SEEK with the second half of the aligned window as overlap
-            if (tid == 0) static_cast<FxFrameHead &>(frames[job.frame_base + nfr]) = fr;
+            if (tid == 0) static_cast<FxFrameHead &>(frames[job.frame_base + fbase + nfr]) = fr;
             nfr++;
             span_pos = a0 + FX_NFFT; span_floor = floor_; span_flags = FX_FLAG_SPAN_EXACT;
             pos = a0 + FX_NFFT; fresh = false; moved = true;
@@ -511,6 +577,17 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
         if (!moved) { pos += (int64_t)FX_HOP * nh; fresh = false; }
     }
 
+    if (fbase) {                                                        // a re-walk that never met its old list: its frames to the front
+        __syncthreads();
+        FxFrame *FW = frames + job.frame_base;
+        for (uint32_t i0 = 0; i0 < nfr; i0 += NT) {
+            const uint32_t i = i0 + tid; FxFrame t;
+            if (i < nfr) t = FW[fbase + i];
+            __syncthreads();
+            if (i < nfr) FW[i] = t;
+            __syncthreads();
+        }
+    }
     if (tid == 0) {
         FxWalkResult r;
         r.n_frames = nfr; r.exit_code = exit_code; r.pos = pos; r.floor = floor_; r.fresh = fresh ? 1u : 0u;
