@@ -119,25 +119,73 @@ FX_DEV float atan2c(float y, float x)
 }
 
 // ---------------------------------------------------------------- 8-point DFT in registers
+// Packed fp32 (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32: one instruction per complex add, two per complex multiply), written
+// as inline assembly because what makes them pay is the operand modifiers: op_sel / op_sel_hi pick which half of a register pair
+// feeds the low / high result, neg_lo / neg_hi negate it -- so a multiplication by -j, a conjugate, a swap of real and imaginary
+// part or the (x + y, y - x) of a 45-degree twiddle cost nothing, where the compiler spends a v_mov per swizzle (60 of the 258
+// VALU instructions per detector bin before this).  Every component is still ONE IEEE operation of the canonical order (DESIGN.md
+// section 4): a - b is a + (-b), -((x + y) c) is (-(x + y)) c, bit for bit.
 #define FX_C8 0.70710678118654752f
-FX_DEV void dft4(float2 c0, float2 c1, float2 c2, float2 c3, float2 &o0, float2 &o1, float2 &o2, float2 &o3)
+typedef float fx_v2 __attribute__((ext_vector_type(2)));
+FX_DEV fx_v2 to_v2(float2 a) { fx_v2 r; r.x = a.x; r.y = a.y; return r; }
+FX_DEV float2 to_f2(fx_v2 a) { return make_float2(a.x, a.y); }
+FX_DEV fx_v2 pk_add(fx_v2 a, fx_v2 b) { fx_v2 o; asm("v_pk_add_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
+FX_DEV fx_v2 pk_sub(fx_v2 a, fx_v2 b) { fx_v2 o; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b)); return o; }
+// a + (-j) b = a + (b.y, -b.x)          and a - (-j) b
+FX_DEV fx_v2 pk_add_mj(fx_v2 a, fx_v2 b) { fx_v2 o; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(o) : "v"(a), "v"(b)); return o; }
+FX_DEV fx_v2 pk_sub_mj(fx_v2 a, fx_v2 b) { fx_v2 o; asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(o) : "v"(a), "v"(b)); return o; }
+// (t.y - t.x, t.x + t.y)
+FX_DEV fx_v2 pk_rot7(fx_v2 t) { fx_v2 o; asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1]" : "=v"(o) : "v"(t)); return o; }
+FX_DEV fx_v2 pk_scale(fx_v2 a, fx_v2 c) { fx_v2 o; asm("v_pk_mul_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(c)); return o; }
+// (a.x c.x, -(a.y c.y))
+FX_DEV fx_v2 pk_scale_conj(fx_v2 a, fx_v2 c) { fx_v2 o; asm("v_pk_mul_f32 %0, %1, %2 neg_hi:[1,0]" : "=v"(o) : "v"(a), "v"(c)); return o; }
+// a * w, component for component what cmul() computes: t = a.y w.y, u = a.y w.x; (fma(a.x, w.x, -t), fma(a.x, w.y, u))
+FX_DEV fx_v2 pk_cmul(fx_v2 a, fx_v2 w)
 {
-    float2 d0 = cadd(c0, c2), d1 = cadd(c1, c3), d2 = csub(c0, c2), e = csub(c1, c3);
-    float2 d3 = make_float2(e.y, -e.x);
-    o0 = cadd(d0, d1); o2 = csub(d0, d1);
-    o1 = cadd(d2, d3); o3 = csub(d2, d3);
+    fx_v2 m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(m) : "v"(a), "v"(w));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(w), "v"(m));
+    return r;
+}
+// a * conj(b) with real and imaginary part swapped (the inverse transform by a forward one), component for component what
+// cmulc() computes: t = a.y b.y, u = a.x b.y; y = (fma(a.x, b.x, t), fma(a.y, b.x, -u)); result (y.y, y.x)
+FX_DEV fx_v2 pk_cmulc_swap(fx_v2 a, fx_v2 b)
+{
+    fx_v2 m, r;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(m) : "v"(a), "v"(b));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,0,1] neg_lo:[0,0,1]" : "=v"(r) : "v"(a), "v"(b), "v"(m));
+    return r;
+}
+FX_DEV void dft4(fx_v2 c0, fx_v2 c1, fx_v2 c2, fx_v2 c3, fx_v2 &o0, fx_v2 &o1, fx_v2 &o2, fx_v2 &o3)
+{
+    const fx_v2 d0 = pk_add(c0, c2), d1 = pk_add(c1, c3), d2 = pk_sub(c0, c2), e = pk_sub(c1, c3);
+    o0 = pk_add(d0, d1); o2 = pk_sub(d0, d1);
+    o1 = pk_add_mj(d2, e); o3 = pk_sub_mj(d2, e);
+}
+FX_DEV void dft8(fx_v2 a[8])
+{
+    const fx_v2 c8 = { FX_C8, FX_C8 };
+    const fx_v2 b0 = pk_add(a[0], a[4]), b4 = pk_sub(a[0], a[4]);
+    const fx_v2 b1 = pk_add(a[1], a[5]), t5 = pk_sub(a[1], a[5]);
+    const fx_v2 b2 = pk_add(a[2], a[6]), t6 = pk_sub(a[2], a[6]);
+    const fx_v2 b3 = pk_add(a[3], a[7]), t7 = pk_sub(a[3], a[7]);
+    const fx_v2 b5 = pk_scale(pk_add_mj(t5, t5), c8);             // ((t5.x + t5.y) c, (t5.y - t5.x) c)
+    const fx_v2 b7 = pk_scale_conj(pk_rot7(t7), c8);              // ((t7.y - t7.x) c, -((t7.x + t7.y) c))
+    dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+    {   // dft4(b4, b5, b6, b7) with b6 = -j t6 folded into its two uses
+        const fx_v2 d0 = pk_add_mj(b4, t6), d2 = pk_sub_mj(b4, t6), d1 = pk_add(b5, b7), e = pk_sub(b5, b7);
+        a[1] = pk_add(d0, d1); a[5] = pk_sub(d0, d1);
+        a[3] = pk_add_mj(d2, e); a[7] = pk_sub_mj(d2, e);
+    }
 }
 FX_DEV void dft8(float2 a[8])
 {
-    float2 b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
-    float2 b1 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]);
-    float2 b2 = cadd(a[2], a[6]), t6 = csub(a[2], a[6]);
-    float2 b3 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
-    float2 b5 = make_float2((t5.x + t5.y) * FX_C8, (t5.y - t5.x) * FX_C8);
-    float2 b6 = make_float2(t6.y, -t6.x);
-    float2 b7 = make_float2((t7.y - t7.x) * FX_C8, -((t7.x + t7.y) * FX_C8));
-    dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
-    dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+    fx_v2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = to_v2(a[i]);
+    dft8(v);
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = to_f2(v[i]);
 }
 
 // ---------------------------------------------------------------- FFT-512 by one wavefront
@@ -146,33 +194,42 @@ FX_DEV void dft8(float2 a[8])
 // scr: 576 float2 of LDS private to the wave (8 rows of 72: 64 data + 8 pad, conflict-free for
 //      both ds_write_b64 and ds_read_b64 in either exchange).
 // twA[r-1] = W512^(lane r), twB[s-1] = W512^(8 (lane&7) s), r,s = 1..7.
-FX_DEV void fft512_wave(float2 a[8], float2 *scr, int lane, const float2 twA[7], const float2 twB[7])
+FX_DEV void fft512_wave(fx_v2 a[8], float2 *scr, int lane, const float2 twA[7], const float2 twB[7])
 {
     dft8(a);
 #pragma unroll
-    for (int r = 1; r < 8; r++) a[r] = cmul(a[r], twA[r - 1]);
+    for (int r = 1; r < 8; r++) a[r] = pk_cmul(a[r], to_v2(twA[r - 1]));
 #pragma unroll
-    for (int r = 0; r < 8; r++) scr[r * 72 + lane] = a[r];
+    for (int r = 0; r < 8; r++) scr[r * 72 + lane] = to_f2(a[r]);
     __builtin_amdgcn_wave_barrier();
     {
         const int r = lane >> 3, j0 = lane & 7;
 #pragma unroll
-        for (int p = 0; p < 8; p++) a[p] = scr[r * 72 + j0 + 8 * p];
+        for (int p = 0; p < 8; p++) a[p] = to_v2(scr[r * 72 + j0 + 8 * p]);
         __builtin_amdgcn_wave_barrier();
         dft8(a);
 #pragma unroll
-        for (int s = 1; s < 8; s++) a[s] = cmul(a[s], twB[s - 1]);
+        for (int s = 1; s < 8; s++) a[s] = pk_cmul(a[s], to_v2(twB[s - 1]));
 #pragma unroll
-        for (int s = 0; s < 8; s++) scr[r * 72 + s * 9 + j0] = a[s];
+        for (int s = 0; s < 8; s++) scr[r * 72 + s * 9 + j0] = to_f2(a[s]);
     }
     __builtin_amdgcn_wave_barrier();
     {
         const int r = lane >> 3, s = lane & 7;
 #pragma unroll
-        for (int j0 = 0; j0 < 8; j0++) a[j0] = scr[r * 72 + s * 9 + j0];
+        for (int j0 = 0; j0 < 8; j0++) a[j0] = to_v2(scr[r * 72 + s * 9 + j0]);
         __builtin_amdgcn_wave_barrier();
         dft8(a);
     }
+}
+FX_DEV void fft512_wave(float2 a[8], float2 *scr, int lane, const float2 twA[7], const float2 twB[7])
+{
+    fx_v2 v[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) v[i] = to_v2(a[i]);
+    fft512_wave(v, scr, lane, twA, twB);
+#pragma unroll
+    for (int i = 0; i < 8; i++) a[i] = to_f2(v[i]);
 }
 
 // balanced-tree sum across the 64 lanes (xor butterfly; a+b is commutative bit-for-bit)

@@ -128,11 +128,11 @@ template <class LDS> __device__ __forceinline__ bool seek_sweep(LDS &L, float x2
     // first maximum in (bin, lag) order.
     float bv = -1.0f; uint32_t bo = 0xFFFFFFFFu;
     for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += LDS::WAVES) {
+        fx_v2 a[8];
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int i = lane + 64 * q;
-            float2 y = cmulc(L.X[i], L.S[(i - off) & (FX_NFFT - 1)]);
-            a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
+            a[q] = pk_cmulc_swap(to_v2(L.X[i]), to_v2(L.S[(i - off) & (FX_NFFT - 1)]));        // swap: inverse via forward FFT
         }
         fft512_wave(a, L.scr[wave], lane, twA, twB);
         float mo = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);     // |R|^2, R = (a.y, a.x)
@@ -280,13 +280,14 @@ __device__ __forceinline__ bool seek_sweep_wave(const float2 *w, const float2 *S
         __builtin_amdgcn_wave_barrier();
     }
     float bv = -1.0f; uint32_t bo = 0xFFFFFFFFu;
+    fx_v2 xv2[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) xv2[q] = to_v2(xn[q]);
 #pragma unroll 1
     for (int off = -FX_RANGE; off <= FX_RANGE; off++) {
+        fx_v2 a[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
-            const float2 y = cmulc(xn[q], S[(lane + 64 * q - off) & (FX_NFFT - 1)]);
-            a[q] = make_float2(y.y, y.x);                     // swap: inverse via forward FFT
-        }
+        for (int q = 0; q < 8; q++) a[q] = pk_cmulc_swap(xv2[q], to_v2(S[(lane + 64 * q - off) & (FX_NFFT - 1)]));    // swap: inverse via forward FFT
         fft512_wave(a, scr, lane, twA, twB);
         float mo = fmaf(a[0].y, a[0].y, a[0].x * a[0].x);     // |R|^2, R = (a.y, a.x)
 #pragma unroll
@@ -604,7 +605,7 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
 // MODE is a template parameter so that the detector-only instance (frame_detector_cc) carries none of the
 // header-recovery code or its registers.
 #ifndef FX_DETECT_OCC
-#define FX_DETECT_OCC 3      // waves per SIMD the detector-only instance (and the seek verifier) is compiled for
+#define FX_DETECT_OCC 4      // waves per SIMD the detector-only instance (and the seek verifier) is compiled for: 128 VGPRs, 4 x 39 KB of LDS per CU
 #endif
 #ifndef FX_FLEX_OCC
 #define FX_FLEX_OCC 2        // same for the flex_rx instance

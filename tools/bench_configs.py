@@ -92,7 +92,7 @@ def run_rank(a, key, rank, world, dist, rdev, stub):
     out["iq_bytes_this_rank"] = int(sum(x.numel() for x, _ in data) * 8)
     counts = [n] * len(groups[0])
     mode = fx.MODE_DETECTOR if cfg["detect"] else fx.MODE_FLEX_RX
-    ctx = fx.RxContext(len(groups[0]), mode=mode, device=dev, threshold=0.45 if cfg["detect"] else 0.0)
+    ctx = fx.RxContext(len(groups[0]), mode=mode, device=dev, threshold=0.45 if cfg["detect"] else 0.0, segment_len=a.segment_len)
     n_inj = n_found = n_ok = n_frames = 0
     for gi, (x, inj) in enumerate(data):                      # (first touch sizes arenas and grids; also the correctness check)
         ctx.reset(); ctx.process_raw(ptrs[gi], counts, True)
@@ -166,6 +166,7 @@ def parse(argv=None):
     ap.add_argument("--streams", type=int, default=0, help="override the config's stream count (rehearsals)")
     ap.add_argument("--samples", type=int, default=0, help="override samples per stream (rehearsals)")
     ap.add_argument("--group", type=int, default=0, help="streams per context call")
+    ap.add_argument("--segment-len", type=int, default=0, help="walker segment length in samples (0: the library's own choice)")
     ap.add_argument("--allow-missing", action="store_true", help="report a rate even if an injected frame was not found (low SNR experiments)")
     return ap.parse_args(argv)
 
