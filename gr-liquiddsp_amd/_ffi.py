@@ -80,7 +80,7 @@ EXPORTS = [
     "flexframegenprops_init_default", "flexframegen_create", "flexframegen_destroy", "flexframegen_setprops",
     "flexframegen_assemble", "flexframegen_getframelen", "flexframegen_write_samples", "fxrx_gen_set_delay",
     "fxrx_last_error", "fxrx_version", "fxrx_device_count", "fxrx_create", "fxrx_destroy", "fxrx_reset",
-    "fxrx_process", "fxrx_result", "fxrx_set_depth", "fxrx_submit", "fxrx_collect", "fxrx_debug_stamps", "fxrx_debug_chain_stamps", "fxrx_debug_walk_stamps", "fxrx_debug_walk_maxjob", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
+    "fxrx_process", "fxrx_result", "fxrx_set_depth", "fxrx_submit", "fxrx_collect", "fxrx_debug_stamps", "fxrx_debug_chain_stamps", "fxrx_debug_walk_stamps", "fxrx_debug_walk_maxjob", "fxrx_debug_walk_jobs", "fxrx_device_framesyms", "fxrx_last_timing", "fxrx_stream", "fxrx_gen_frame_len",
     "fxrx_mod_from_index", "fxrx_mod_to_index", "fxrx_inner_from_index", "fxrx_inner_to_index",
     "fxrx_outer_from_index", "fxrx_outer_to_index",
     "fxtx_create", "fxtx_destroy", "fxtx_frame_len", "fxtx_generate",
@@ -176,6 +176,7 @@ def lib():
     L.fxrx_debug_chain_stamps.restype = C.c_int; L.fxrx_debug_chain_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint32 * 8)]
     L.fxrx_debug_walk_stamps.restype = C.c_int; L.fxrx_debug_walk_stamps.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 4)]
     L.fxrx_debug_walk_maxjob.restype = C.c_int; L.fxrx_debug_walk_maxjob.argtypes = [C.c_void_p, C.POINTER(C.c_uint64 * 8)]
+    L.fxrx_debug_walk_jobs.restype = C.c_int; L.fxrx_debug_walk_jobs.argtypes = [C.c_void_p, C.c_void_p, C.c_uint]
     L.fxrx_device_framesyms.restype = C.c_void_p; L.fxrx_device_framesyms.argtypes = [C.c_void_p, C.POINTER(C.c_uint64)]
     L.fxrx_last_timing.restype = C.c_int; L.fxrx_last_timing.argtypes = [C.c_void_p, C.POINTER(Timing)]
     L.fxrx_stream.restype = C.c_void_p; L.fxrx_stream.argtypes = [C.c_void_p]

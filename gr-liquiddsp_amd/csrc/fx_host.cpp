@@ -194,6 +194,7 @@ struct fxrx_ctx_s {
     FxTables *d_tables = nullptr;
     std::vector<StreamState> st;
     FxStreamState *d_state = nullptr; FxStreamState *h_state = nullptr;   // [kStateRing][n_streams], device / pinned mirror
+    float taper = -1.0f;                 // FXRX_TAPER: segment lengths of a stream fall from (1 + t) to (1 - t) times the mean (-1: chosen per block)
     bool skip_seek = true;               // FXRX_SKIP_SEEK=0: walkers run the full detector on every hop (nothing to verify)
     bool chain_slow = false;             // FXRX_CHAIN_SLOW=1: every block goes through the full-size chain kernel's general (sequential) path
     unsigned pll_waves = 1, dec_waves = 1;   // waves per workgroup of the PLL / decode grids (placement only)
@@ -212,6 +213,7 @@ struct fxrx_ctx_s {
     int inchain_repair = 1; unsigned inchain_left = 0;
     int timing_level = -1;               // stage events per block: -1 auto (all stages one block at a time, none with blocks in flight) | 0 none | 1 the PLL only | 2 all stages
     hipEvent_t ref_event = nullptr; double ref_host_ms = 0.0;   // fxrx_debug_block_times: a common origin of GPU and host clocks
+    int debug_walk_twice = 0;            // FXRX_DEBUG_WALK_TWICE: the speculative walkers are launched twice, the stage time is the second launch's (cold-start experiment)
     int debug_stop_after = 0;            // FXRX_DEBUG_STOP_AFTER (tools/dev/dev_stage_cost.py): 4 plan | 5 matched filter | 6 PLL -- the chain ends there, no results
     uint64_t vbfix_hint = 0;             // the last collected block's batch Viterbi path ran blocks again / handed frames back: the hand-over check is launched with the next one
     uint64_t fb_hint = 0;                // frames the last collected block's batch Viterbi path handed back (sizes the fallback launch; 0: none enqueued)
@@ -361,10 +363,12 @@ fxrx_ctx *fxrx_create(const fxrx_config *cfg)
     if (const char *e = std::getenv("FXRX_PLL_WAVES")) c->pll_waves = (unsigned)std::min(4, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_DEC_WAVES")) c->dec_waves = (unsigned)std::min(8, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_SKIP_SEEK")) c->skip_seek = std::atoi(e) != 0;
+    if (const char *e = std::getenv("FXRX_TAPER")) c->taper = std::min(0.95f, (float)std::atof(e));
     if (const char *e = std::getenv("FXRX_CHAIN_SLOW")) c->chain_slow = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_BATCH_VITERBI")) c->batch_viterbi = std::atoi(e) != 0;
     if (const char *e = std::getenv("FXRX_INCHAIN_REPAIR")) c->inchain_repair = std::min(2, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_DEBUG_STOP_AFTER")) c->debug_stop_after = std::atoi(e);
+    if (const char *e = std::getenv("FXRX_DEBUG_WALK_TWICE")) c->debug_walk_twice = std::atoi(e);
     if (const char *e = std::getenv("FXRX_TIMING")) c->timing_level = std::min(2, std::max(0, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_WALK_PER_CU")) c->walk_per_cu = (uint32_t)std::min(8, std::max(1, std::atoi(e)));
     if (const char *e = std::getenv("FXRX_VERIFY_PER_CU")) c->verify_per_cu = (uint32_t)std::min(64, std::max(1, std::atoi(e)));
@@ -467,6 +471,14 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         seg = std::max<uint64_t>(seg, 32768); seg = std::min<uint64_t>(seg, 1u << 20);
     }
     seg = std::max<uint64_t>(seg, 4096);
+    // (detector-only mode with more jobs than fit on the chip at once: config 3 alone 28.7 -> 24.7 ms; the flex_rx walker, whose launches
+    // overlap the rest of the chain, gains nothing from it: configs 4, 5 and 2 measured equal or worse)
+    float taper = c->taper;
+    if (taper < 0.0f) {
+        uint64_t tot = 0;
+        for (unsigned s = 0; s < NS; s++) tot += sl.n[s];
+        taper = (detect && tot / seg > 4ull * (uint64_t)c->n_cus) ? 0.75f : 0.0f;
+    }
     std::vector<FxWalkJob> jobs; std::vector<uint32_t> early, late; std::vector<FxStreamDesc> sds(NS);
     uint32_t frame_slots = 0, chain_slots = 0; uint64_t n_total = 0, carry_total = 0;
     for (unsigned s = 0; s < NS; s++) {
@@ -485,11 +497,23 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         // late (after the previous block's chain kernel) while the speculative walkers of the other segments are long under way
         int64_t p = 0; bool first = true;
         const int64_t seg0 = cont ? (int64_t)std::min<uint64_t>(seg, 8192) : (int64_t)seg;
+        // Tapered segments: what is launched last is short.  A walker workgroup alone on its CU runs at well under half the rate four
+        // of them reach together (tools/dev/dev_walk_timeline.py), so the last jobs of a launch set the length of its drain.
+        const int64_t p_t = cont ? std::min<int64_t>(ns, seg0) : 0;                       // the taper covers [p_t, ns)
+        const int64_t k_t = taper > 0.0f ? std::max<int64_t>(1, ((ns - p_t) + (int64_t)seg / 2) / (int64_t)seg) : 0;
+        int64_t i_t = 0;
         while (first || p < ns) {
             FxWalkJob j{};
             j.x = sd.x; j.xa_end = sd.xa_end; j.n = ns; j.start = p;
             j.stop = std::min<int64_t>(ns, p + (first ? seg0 : (int64_t)seg));
             if (ns - j.stop < (int64_t)seg / 2) j.stop = ns;          // fold a short last segment in
+            if (k_t > 1 && p >= p_t) {
+                // piece i of k: boundary at the integral of the falling line (1 + t) -> (1 - t)
+                const double u = (double)(i_t + 1) / (double)k_t;
+                const int64_t e = p_t + (int64_t)((double)(ns - p_t) * (u * (1.0 + taper) - taper * u * u));
+                j.stop = (i_t + 1 >= k_t) ? ns : std::min<int64_t>(ns, std::max<int64_t>(p + 4096, e & ~(int64_t)255));
+                i_t++;
+            }
             j.fresh = 1u; j.floor = p;
             j.mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
             j.handoff = j.stop < ns ? 1u : 0u;
@@ -511,6 +535,8 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
         n_total += (uint64_t)ns; carry_total += cont ? (uint64_t)sn.carry_bound : 0u;
     }
     for (unsigned s = 0; s < NS; s++) { sds[s].repair_base = frame_slots; sds[s].repair_cap = kRepairCap; frame_slots += kRepairCap; }
+    if (taper > 0.0f)
+        std::stable_sort(early.begin(), early.end(), [&](uint32_t a, uint32_t b2) { return jobs[a].stop - jobs[a].start > jobs[b2].stop - jobs[b2].start; });
     const size_t NJ = jobs.size();
     sl.NJ = NJ; sl.n_early = early.size(); sl.n_late = late.size(); sl.any_late = !late.empty();
     sl.frame_slots = frame_slots; sl.chain_cap = chain_slots;
@@ -580,6 +606,8 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
     const int tl = c->timing_level >= 0 ? c->timing_level : (c->depth > 1 ? 0 : 2);      // stage events: see fxrx_set_timing
     sl.timing_level = tl;
+    for (int rep = 0; rep < c->debug_walk_twice; rep++)
+        HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ, nullptr, 0u));
     if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[0], st));
     HIP_OK(fx_launch_walk(mode, c->cfg.equalizer ? 1 : 0, (unsigned)early.size(), st, d_jobs, d_list, sl.d_wres.p, sl.d_frames.p, sl.d_runs.p, sl.run_cap, sl.d_hdr.p, c->d_tables, 0, (uint32_t)NJ, nullptr, 0u));
     // the true walkers of continuing streams read the state the previous block's chain kernel leaves.  What the speculative
@@ -1146,6 +1174,17 @@ static int walk_stamps(const fxrx_ctx *c, uint64_t sum[4], uint64_t maxjob[8])
     }
 #endif
     return 0;
+}
+// diagnostic builds: per walk job of the last collected block 6 words -- stamp[0..3], hops, frames (detector-only mode: start / end on the
+// 100 MHz wall clock, CU id, 0); returns the number of jobs
+int fxrx_debug_walk_jobs(const fxrx_ctx *c, uint32_t *out, unsigned int cap_jobs)
+{
+    if (!c || !out || !c->last) return FXRX_ERR_ARG;
+    const size_t nj = std::min<size_t>(c->last->NJ, cap_jobs);
+    std::vector<FxWalkResult> r(nj);
+    if (nj && hipMemcpy(r.data(), c->last->d_wres.p, nj * sizeof(FxWalkResult), hipMemcpyDeviceToHost) != hipSuccess) return FXRX_ERR_HIP;
+    for (size_t i = 0; i < nj; i++) { for (int k = 0; k < 4; k++) out[6 * i + k] = r[i].stamp[k]; out[6 * i + 4] = r[i].hops; out[6 * i + 5] = r[i].n_frames; }
+    return (int)nj;
 }
 // shader clocks of the chain kernel's phases (stream 0) of the last collected block: whole fast path, -, pointer chase, kernel total
 int fxrx_debug_chain_stamps(const fxrx_ctx *c, uint32_t out[8]) { if (!c || !c->last) return FXRX_ERR_ARG; std::memcpy(out, c->last->h_hdr.p->stamp, 8 * sizeof(uint32_t)); return 0; }

@@ -324,6 +324,9 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
 {
     constexpr int NT = 64 * WW;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef FX_STAMPS
+    const uint32_t wall0_ = (uint32_t)wall_clock64();           // job timeline (tools/dev/dev_walk_timeline.py): start, end (100 MHz), CU
+#endif
     const XSrc xs = { job.x, job.xa_end, job.n };
     const int64_t n = job.n;
     int64_t pos = job.start, floor_ = job.floor, stop = job.stop;
@@ -597,6 +600,9 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
         r.tail_pos = span_pos; r.tail_floor = span_floor; r.handoff_pos = ho_pos; r.handoff_clear = ho_clear;
         r.tail_flags = span_flags;
         for (int i = 0; i < 4; i++) r.stamp[i] = 0;
+#ifdef FX_STAMPS
+        r.stamp[0] = wall0_; r.stamp[1] = (uint32_t)wall_clock64(); r.stamp[2] = __smid();
+#endif
         *result = r;
         atomicAdd(&hdr->hops, hops); atomicAdd(&hdr->walk_jobs_run, 1u);
     }

@@ -217,6 +217,7 @@ int fxrx_debug_stamps(const fxrx_ctx *c, unsigned int i, uint32_t out[8]);
 int fxrx_debug_chain_stamps(const fxrx_ctx *c, uint32_t out[8]);  /* chain kernel phase clocks (stream 0) of the last collected block */
 int fxrx_debug_walk_stamps(const fxrx_ctx *c, uint64_t out[4]);   /* summed walker phase clocks: coarse, seek, align, header */
 int fxrx_debug_walk_maxjob(const fxrx_ctx *c, uint64_t out[8]);   /* slowest walk job: 4 phase clocks, hops, coarse hops, frames, total */
+int fxrx_debug_walk_jobs(const fxrx_ctx *c, uint32_t *out, unsigned int cap_jobs);   /* per walk job 6 words: 4 stamps, hops, frames; returns the job count */
 /* device-resident payload symbols / hard decisions of the last call (NULL if none) */
 const void *fxrx_device_framesyms(const fxrx_ctx *c, uint64_t *n_symbols);
 
