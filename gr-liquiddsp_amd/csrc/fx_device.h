@@ -222,6 +222,37 @@ FX_DEV void fft512_wave(fx_v2 a[8], float2 *scr, int lane, const float2 twA[7], 
         dft8(a);
     }
 }
+// two independent transforms by the same wave, stage by stage side by side: one transform alone is a chain of LDS round trips and
+// dependent butterflies that a lone wave on its SIMD cannot hide (the flex_rx walker: one workgroup per CU); two give the scheduler
+// something to put into the gaps.  Same arithmetic per transform.
+FX_DEV void fft512_wave2(fx_v2 a[8], fx_v2 b[8], float2 *scrA, float2 *scrB, int lane, const float2 twA[7], const float2 twB[7])
+{
+    dft8(a); dft8(b);
+#pragma unroll
+    for (int r = 1; r < 8; r++) { a[r] = pk_cmul(a[r], to_v2(twA[r - 1])); b[r] = pk_cmul(b[r], to_v2(twA[r - 1])); }
+#pragma unroll
+    for (int r = 0; r < 8; r++) { scrA[r * 72 + lane] = to_f2(a[r]); scrB[r * 72 + lane] = to_f2(b[r]); }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int r = lane >> 3, j0 = lane & 7;
+#pragma unroll
+        for (int p = 0; p < 8; p++) { a[p] = to_v2(scrA[r * 72 + j0 + 8 * p]); b[p] = to_v2(scrB[r * 72 + j0 + 8 * p]); }
+        __builtin_amdgcn_wave_barrier();
+        dft8(a); dft8(b);
+#pragma unroll
+        for (int s = 1; s < 8; s++) { a[s] = pk_cmul(a[s], to_v2(twB[s - 1])); b[s] = pk_cmul(b[s], to_v2(twB[s - 1])); }
+#pragma unroll
+        for (int s = 0; s < 8; s++) { scrA[r * 72 + s * 9 + j0] = to_f2(a[s]); scrB[r * 72 + s * 9 + j0] = to_f2(b[s]); }
+    }
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int r = lane >> 3, s = lane & 7;
+#pragma unroll
+        for (int j0 = 0; j0 < 8; j0++) { a[j0] = to_v2(scrA[r * 72 + s * 9 + j0]); b[j0] = to_v2(scrB[r * 72 + s * 9 + j0]); }
+        __builtin_amdgcn_wave_barrier();
+        dft8(a); dft8(b);
+    }
+}
 FX_DEV void fft512_wave(float2 a[8], float2 *scr, int lane, const float2 twA[7], const float2 twB[7])
 {
     fx_v2 v[8];

@@ -35,15 +35,17 @@
 
 template <int WW> struct WalkLdsT {
     static constexpr int WAVES = WW;
+    static constexpr bool SWEEP_PAIRS = WW == 4;   // the detector sweep takes two bins per wave at a time (seek_sweep)
     float2 win[FX_NFFT];            // time window of the current hop / aligned window
     float2 X[FX_NFFT];              // its spectrum
     float2 S[FX_NFFT];              // template spectrum
     float2 scr[WW][576];            // per-wave FFT exchange buffers
-    float2 v[640];                  // mixed-down samples of the preamble+header span
-    float2 P[256];                  // x conj(s) products (ALIGN)
-    float  m2[FX_NFFT];
+    float2 v[640];                  // mixed-down samples of the preamble+header span  } dead during a detector sweep: v, P, m2 together
+    float2 P[256];                  // x conj(s) products (ALIGN)                      } are exactly two more exchange buffers,
+    float  m2[FX_NFFT];             //                                                 } cw another two (scr2)
     float2 hdr[FX_HDR_SYM];
     float2 cw[(WW + 1) * FX_HOP + 8];   // coarse scan: overlap half + one new hop per wave
+    __device__ __forceinline__ float2 *scr2(int wave) { return wave < 2 ? v + 576 * wave : cw + 576 * (wave - 2); }
     float2 pb[16];                  // de-rotated pilots
     float2 eqw[16];                 // equaliser taps (equaliser stage on)
     float  taps[FX_MF_TAPS];
@@ -61,6 +63,8 @@ template <int WW> struct WalkLdsT {
 // and PLL grids, the longest stage of a block, queue behind them.
 template <int WW> struct SeekLdsT {
     static constexpr int WAVES = WW;
+    static constexpr bool SWEEP_PAIRS = false;     // (four verifier workgroups share a CU: nothing to gain, 18 KB of LDS to lose)
+    __device__ __forceinline__ float2 *scr2(int) { return nullptr; }
     float2 win[FX_NFFT], X[FX_NFFT], S[FX_NFFT];
     float2 scr[WW][576];
     float  redf[WW < 4 ? 4 : WW]; float2 redc[WW < 4 ? 4 : WW];
@@ -127,6 +131,29 @@ template <class LDS> __device__ __forceinline__ bool seek_sweep(LDS &L, float x2
     // more transform of the winning bin (same arithmetic, so the value is found again exactly).  Tie rule as before:
     // first maximum in (bin, lag) order.
     float bv = -1.0f; uint32_t bo = 0xFFFFFFFFu;
+    if constexpr (LDS::SWEEP_PAIRS) {
+        // two bins of this wave at a time (off, off + WAVES), their transforms side by side; the odd one out is done twice
+        float2 *scrB = L.scr2(wave);
+        for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += 2 * LDS::WAVES) {
+            const bool two = off + LDS::WAVES <= FX_RANGE;
+            const int off2 = two ? off + LDS::WAVES : off;
+            fx_v2 a[8], b[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const int i = lane + 64 * q;
+                const fx_v2 x = to_v2(L.X[i]);
+                a[q] = pk_cmulc_swap(x, to_v2(L.S[(i - off) & (FX_NFFT - 1)]));                 // swap: inverse via forward FFT
+                b[q] = pk_cmulc_swap(x, to_v2(L.S[(i - off2) & (FX_NFFT - 1)]));
+            }
+            fft512_wave2(a, b, L.scr[wave], scrB, lane, twA, twB);
+            float mo = fmaf(a[0].y, a[0].y, a[0].x * a[0].x), mo2 = fmaf(b[0].y, b[0].y, b[0].x * b[0].x);
+#pragma unroll
+            for (int t = 1; t < 8; t++) { mo = fmaxf(mo, fmaf(a[t].y, a[t].y, a[t].x * a[t].x)); mo2 = fmaxf(mo2, fmaf(b[t].y, b[t].y, b[t].x * b[t].x)); }
+            if (mo > bv) { bv = mo; bo = (uint32_t)(off + FX_RANGE); }       // bins ascend per wave: first maximum kept
+            if (two && mo2 > bv) { bv = mo2; bo = (uint32_t)(off2 + FX_RANGE); }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else
     for (int off = -FX_RANGE + wave; off <= FX_RANGE; off += LDS::WAVES) {
         fx_v2 a[8];
 #pragma unroll
@@ -624,12 +651,14 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
 // segment as well (a few times at most, and while its frame table has room).
 template <int MODE, int WW, bool EQ, bool EXT = false>
 __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_index, FxWalkResult *result, FxFrame *frames, FxVerifyRun *runs,
-                                         uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T, WalkLdsT<WW> &L,
+                                         uint32_t run_cap, FxBlockHdr *hdr, const FxTables *T_in, WalkLdsT<WW> &L,
                                          const float2 (&twA)[7], const float2 (&twB)[7],
                                          const FxWalkJob *all_jobs = nullptr, const FxWalkResult *all_results = nullptr, uint32_t n_jobs_total = 0)
 {
     constexpr int WALK_WAVES = WW, WALK_THREADS = 64 * WW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const FxTables *T = T_in;
+    const int tid_in = threadIdx.x;
+    const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
     const XSrc xs = { job.x, job.xa_end, job.n };
     const int64_t n = job.n;
 
@@ -693,6 +722,16 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
     __syncthreads();
 
     for (;;) {
+        // The table pointer is made opaque once per turn of the state machine: left alone, the compiler computes every lane-dependent
+        // table address of every phase (some forty 64-bit pointers: T->TD[k + 64 t], the gather tables, ...) once, in front of this
+        // loop, and keeps them in vector registers through all phases -- the detector sweep below was left with so few registers that
+        // it read the template spectrum one element at a time, a full LDS round trip each.
+        // Likewise the thread index: every lane-dependent index and byte offset any phase uses (lane | 64 q, 8 (lane + 64 q), ...:
+        // fifty registers) would be computed once and kept; they cost an instruction each where they are used.
+        const FxTables *T = T_in; asm volatile("" : "+s"(T));
+        int tid = tid_in; asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool lo = tid < HALF;
         // the walk state is uniform across the workgroup: say so, so that it lives in scalar registers
         pos = uniform64(pos); floor_ = uniform64(floor_); span_pos = uniform64(span_pos); span_floor = uniform64(span_floor);
         x2_0 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x2_0)));
