@@ -100,7 +100,18 @@ __device__ __forceinline__ int64_t uniform64(int64_t v)
 // previous block right-aligned below 0 (index p < 0 reads xa_end[p]).  Samples below `floor` (before the last
 // synchroniser reset) and beyond the data read as zero; a floor is never below the start of the carried tail.
 struct XSrc { const float2 *x, *xa_end; int64_t n; };
-__device__ __forceinline__ float2 xld(const XSrc &s, int64_t p) { return p < 0 ? s.xa_end[p] : s.x[p]; }
+// the two pointers are the same for the whole workgroup: say so.  (Scalar registers instead of a vector pair each -- and, read
+// straight out of a descriptor in memory where they sit side by side, the compiler turned xld()'s choice between them into an
+// indexed load from a copy of the descriptor in SCRATCH: the 32 bytes of private memory every walker instance had.)
+__device__ __forceinline__ XSrc make_xsrc(const float2 *x, const float2 *xa_end, int64_t n)
+{
+    XSrc s;
+    s.x = reinterpret_cast<const float2 *>(uniform64((int64_t)reinterpret_cast<uintptr_t>(x)));
+    s.xa_end = reinterpret_cast<const float2 *>(uniform64((int64_t)reinterpret_cast<uintptr_t>(xa_end)));
+    s.n = n;
+    return s;
+}
+__device__ __forceinline__ float2 xld(const XSrc &s, int64_t p) { const float2 *a = s.x, *b = s.xa_end; return (p < 0 ? b : a)[p]; }
 __device__ __forceinline__ float2 xv(const XSrc &s, int64_t p, int64_t floor_)
 {
     return (p >= floor_ && p < s.n && (p >= 0 || s.xa_end)) ? xld(s, p) : make_float2(0.0f, 0.0f);
@@ -354,7 +365,7 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
 #ifdef FX_STAMPS
     const uint32_t wall0_ = (uint32_t)wall_clock64();           // job timeline (tools/dev/dev_walk_timeline.py): start, end (100 MHz), CU
 #endif
-    const XSrc xs = { job.x, job.xa_end, job.n };
+    const XSrc xs = make_xsrc(job.x, job.xa_end, job.n);
     const int64_t n = job.n;
     int64_t pos = job.start, floor_ = job.floor, stop = job.stop;
     int ext_left = 6;
@@ -640,6 +651,9 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
 #ifndef FX_DETECT_OCC
 #define FX_DETECT_OCC 4      // waves per SIMD the detector-only instance (and the seek verifier) is compiled for: 128 VGPRs, 4 x 39 KB of LDS per CU
 #endif
+#ifndef FX_VERIFY_OCC
+#define FX_VERIFY_OCC 5      // the seek verifier: 96 VGPRs, 5 x 31 KB of LDS per CU
+#endif
 #ifndef FX_FLEX_OCC
 #define FX_FLEX_OCC 2        // same for the flex_rx instance
 #endif
@@ -659,7 +673,7 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
     const FxTables *T = T_in;
     const int tid_in = threadIdx.x;
     const int tid = tid_in, lane = tid & 63, wave = tid >> 6;
-    const XSrc xs = { job.x, job.xa_end, job.n };
+    const XSrc xs = make_xsrc(job.x, job.xa_end, job.n);
     const int64_t n = job.n;
 
     int64_t pos = job.start, floor_ = job.floor, stop = job.stop;
@@ -1321,7 +1335,7 @@ extern "C" hipError_t fx_launch_walk(unsigned mode, int eq, unsigned njobs, hipS
 // window exactly like the walker does.  A hop that does fire marks the span's owner (a frame-table slot, or a job's
 // tail span) FX_FLAG_SPAN_BAD; fx_chain_kernel then walks that span again with the exact detector on every hop.
 template <int WW>
-__global__ __launch_bounds__(64 * WW, FX_DETECT_OCC)
+__global__ __launch_bounds__(64 * WW, FX_VERIFY_OCC)
 void fx_seekverify_kernel(const FxVerifyRun *runs, uint32_t run_cap, const FxWalkJob *jobs, FxWalkResult *results, FxFrame *frames, FxBlockHdr *hdr,
                           const FxTables *T, uint32_t phase)
 {
@@ -1332,17 +1346,22 @@ void fx_seekverify_kernel(const FxVerifyRun *runs, uint32_t run_cap, const FxWal
     const uint32_t split = min(hdr->runs_done, run_cap);
     const uint32_t run0 = phase ? split : 0u, nruns = phase ? min(hdr->n_runs, run_cap) : split;
     if (run0 + blockIdx.x >= nruns) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid_in = threadIdx.x;
     float2 twA[7], twB[7];
+    {
+        const int tid = tid_in, lane = tid & 63;
 #pragma unroll
-    for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
-    for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
+        for (int r = 1; r < 8; r++) { twA[r - 1] = T->tw[lane * r]; twB[r - 1] = T->tw[8 * (lane & 7) * r]; }
+        for (int i = tid; i < FX_NFFT; i += WALK_THREADS) L.S[i] = T->S[i];
+    }
     const float s2sum = T->s2sum;
-    const bool lo = tid < HALF;
     for (uint32_t ri = run0 + blockIdx.x; ri < nruns; ri += gridDim.x) {
+        int tid = tid_in; asm volatile("" : "+v"(tid));        // (indices are computed where they are used, not kept: see walk_run)
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool lo = tid < HALF;
         const FxVerifyRun run = runs[ri];
         const FxWalkJob &jb = jobs[run.job];
-        const XSrc xs = { jb.x, jb.xa_end, jb.n };
+        const XSrc xs = make_xsrc(jb.x, jb.xa_end, jb.n);
         const float threshold = jb.threshold;
         int64_t pos = run.pos;
         __syncthreads();
@@ -1582,7 +1601,7 @@ __device__ __forceinline__ void chain_finish(const FxStreamDesc &sd, uint32_t s,
                                              bool fin_fresh, uint32_t *chain_count, FxBlockHdr *hdr)
 {
     const int tid = threadIdx.x;
-    const XSrc xs = { sd.x, sd.xa_end, sd.n };
+    const XSrc xs = make_xsrc(sd.x, sd.xa_end, sd.n);
     if (cnt > sd.chain_cap) { if (tid == 0) atomicOr(&hdr->flags, (uint32_t)FX_BLK_CHAIN_FULL); cnt = sd.chain_cap; }
     int64_t keep_from = fin_fresh ? fin_pos : fin_pos - FX_HOP;
     keep_from = max(-st_in.carry_len, min(keep_from, sd.n));
@@ -2140,7 +2159,7 @@ void fx_paymf_kernel(const FxPayJob *jobs, const uint32_t *blk_job, const uint32
         const int64_t nlo = sym_sample(sym0 + c0, job.mfc0) - LEAD - (FX_MF_TAPS - 1);
         const int64_t nhi = sym_sample(sym0 + c0 + ns - 1, job.mfc0);
         const int span = (int)(nhi - nlo + 1);
-        const XSrc xs = { job.x, job.xa_end, 0 };
+        const XSrc xs = make_xsrc(job.x, job.xa_end, 0);
         __syncthreads();
         if (tid < FX_MF_TAPS) taps[tid] = T->proto[job.pfb + FX_NPFB * tid];
         if (EQ && tid < 16) eqw[tid] = tid < FX_EQ_TAPS ? chain[job.chain_idx].eq[tid] : make_float2(0.0f, 0.0f);
