@@ -651,6 +651,12 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
 #ifndef FX_DETECT_OCC
 #define FX_DETECT_OCC 4      // waves per SIMD the detector-only instance (and the seek verifier) is compiled for: 128 VGPRs, 4 x 39 KB of LDS per CU
 #endif
+// register budget of the walker instances ("amdgpu-num-vgpr" counts half of gfx950's unified file: 72 -> 144 VGPRs; the flex_rx
+// instance the bench runs needs no private memory at that, its equaliser / repair-round variants spill a little)
+#ifndef FX_FLEX_VGPRS
+#define FX_FLEX_VGPRS 72
+#endif
+#define FX_WALK_VGPR_ATTR __attribute__((amdgpu_num_vgpr(FX_FLEX_VGPRS)))
 #ifndef FX_VERIFY_OCC
 #define FX_VERIFY_OCC 5      // the seek verifier: 96 VGPRs, 5 x 31 KB of LDS per CU
 #endif
@@ -1279,7 +1285,7 @@ __device__ __forceinline__ void walk_any(const FxWalkJob &job, uint32_t job_inde
 }
 
 template <int MODE, int WW, bool EQ, bool EXT = false>
-__global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC)
+__global__ __launch_bounds__(64 * WW, MODE == FX_MODE_DETECT ? FX_DETECT_OCC : FX_FLEX_OCC) FX_WALK_VGPR_ATTR
 void fx_walk_kernel(const FxWalkJob *jobs, const uint32_t *job_list, FxWalkResult *results, FxFrame *frames, FxVerifyRun *runs, uint32_t run_cap,
                     FxBlockHdr *hdr, const FxTables *T, uint32_t n_jobs_total, const uint32_t *n_list, uint32_t list_cap)
 {
