@@ -818,8 +818,18 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
             if (hw >= 0 && locked) {
                 // candidate in the window of grid hop hw: resume the exact detector there (one hop earlier when the
                 // candidate sits at the very start of the window -- the two correlators may disagree by a sample)
+#ifdef FX_EXACT_HOPS_OLD
                 exact_left = 3;
                 if (L.cand[hw] < 8u && hw > 0) { hw--; exact_left = 4; }
+#else
+                // The exact detector accepts a peak at lags below 512 - 156 only, like this one: a candidate well inside that range is
+                // this very hop's detection or nobody's (a false alarm of the cheap correlator costs ONE sweep of 50 transforms, not
+                // three); near either end of the range the two correlators may place it in the neighbouring hop.  Whatever this misjudges,
+                // the seek verifier finds (every hop of the span is checked there anyway) and the chain kernel repairs.
+                const uint32_t cl_ = L.cand[hw];
+                exact_left = cl_ >= FX_NFFT - FX_S_LEN - 12u ? 2 : 1;
+                if (cl_ < 8u && hw > 0) { hw--; exact_left = 2; }
+#endif
                 hops_cheap -= WALK_WAVES - hw;
                 if (hw > 0) {
                     const float2 w = lo ? L.cw[FX_HOP * hw + tid] : make_float2(0.0f, 0.0f);
@@ -891,7 +901,11 @@ __device__ __forceinline__ void walk_run(const FxWalkJob &job, uint32_t job_inde
             __syncthreads();
             const float cpk = L.f[4]; const uint32_t cl = L.u[8];
             if (cpk > 0.06f * ed * T->td2sum * (float)FX_NFFT * (float)FX_NFFT && ed > 0.0f) {
+#ifdef FX_EXACT_HOPS_OLD
                 if (locked) { coarse_hit = true; exact_left = 3; hops_cheap--; }   // run the exact detector on this very hop
+#else
+                if (locked) { coarse_hit = true; exact_left = cl >= FX_NFFT - FX_S_LEN - 12u ? 2 : 1; hops_cheap--; }   // run the exact detector on this very hop
+#endif
                 else {
                     // candidate preamble at p: the exact detector takes over on the hop whose new half starts at p (see above)
                     const int64_t p = pos - FX_HOP + (int64_t)cl;
