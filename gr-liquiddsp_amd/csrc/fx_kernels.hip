@@ -361,7 +361,8 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
                                            const FxWalkJob *all_jobs, const FxWalkResult *all_results, uint32_t n_jobs_total)
 {
     constexpr int NT = 64 * WW;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid_in = threadIdx.x;
+    const int tid = tid_in;
 #ifdef FX_STAMPS
     const uint32_t wall0_ = (uint32_t)wall_clock64();           // job timeline (tools/dev/dev_walk_timeline.py): start, end (100 MHz), CU
 #endif
@@ -390,7 +391,6 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
     uint32_t span_flags = (fresh ? FX_FLAG_SEEK_FRESH : 0u) | FX_FLAG_SPAN_EXACT;
     const float s2sum = T->s2sum;
     const float2 *sc = T->sc;
-    const bool lo = tid < HALF;
     float2 *win = L.cw, *X = L.cw + FX_NFFT, *P = L.cw + 2 * FX_NFFT; float *m2 = reinterpret_cast<float *>(L.scr[1]);
     // Re-sync (walks of a repair round only): this segment was walked before, speculatively, and is walked again because the true
     // chain enters it in a state its list did not anticipate.  From the first detection the two walks have in common on, the old
@@ -410,6 +410,10 @@ __device__ __forceinline__ void detect_run(const FxWalkJob &job, uint32_t job_in
     const uint32_t fcap = resync ? job.max_frames - fbase : job.max_frames;
 
     for (;;) {
+        // (thread index opaque per round: lane-dependent indices are computed where they are used instead of being kept, see walk_run)
+        int tid = tid_in; asm volatile("" : "+v"(tid));
+        const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const bool lo = tid < HALF;
         pos = uniform64(pos); floor_ = uniform64(floor_);
         nfr = __builtin_amdgcn_readfirstlane(nfr); hops = __builtin_amdgcn_readfirstlane(hops);
         if (pos >= stop && !in_handoff) {
