@@ -641,11 +641,8 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     if (tl >= 2) HIP_OK(hipEventRecord(sl.ev[2], cst));
     // chain kernels run in block order in any case (they write the carry buffers in rotation); this one writes
     // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
-    static const bool dbg_no_order = std::getenv("FXRX_DEBUG_NO_ORDER") != nullptr;      // experiment only: unsafe for continuing streams
-    if (!dbg_no_order) {
     if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
     if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(cst, c->carry_reader[(b + 1) % 3], 0));
-    }
     return enqueue_back(c, sl, kChainFast, cst);
 }
 
