@@ -77,6 +77,8 @@ extern "C" hipError_t fx_launch_paydec(int with_rs, int soft, unsigned first_wav
                                        const uint32_t *job_idx, const FxBlockHdr *hdr, const uint8_t *hard, uint8_t *bufA, uint8_t *bufB, uint8_t *soft_arena,
                                        unsigned long long *dw_arena, uint8_t *out, FxOutRec *recs, FxPayResult *res, const FxTables *T, FxBlockHdr *fallback_host);
 extern "C" hipError_t fx_launch_symcopy(unsigned grid, hipStream_t st, const FxBlockHdr *hdr, const float2 *sym, float2 *host);
+extern "C" hipError_t fx_launch_upload(hipStream_t st, const void *src, void *dst, size_t bytes, unsigned n_cus);
+extern "C" hipError_t fx_launch_copy_u32(hipStream_t st, const uint32_t *src, uint32_t *dst);
 extern "C" hipError_t fx_launch_softdemod(unsigned grid, hipStream_t st, const FxPayJob *jobs, const uint32_t *blk_job, const uint32_t *blk_c0, const FxBlockHdr *hdr,
                                           const float2 *framesyms, const uint8_t *hard, uint8_t *soft_arena, const FxTables *T);
 
@@ -122,6 +124,17 @@ template <class T> struct PinBuf {
     ~PinBuf() { if (p) (void)hipHostFree(p); }
 };
 
+constexpr size_t kUploadKernelMax = 64u << 20;      // host blocks up to this size are uploaded by fx_upload_kernel when their memory is page-locked
+// is p page-locked host memory the device can read, and at which address?
+static bool pinned_device_ptr(const void *p, const void **dev)
+{
+    if (!p || (reinterpret_cast<uintptr_t>(p) & 7u)) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }     // (pageable memory: not an error here)
+    if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+    *dev = a.devicePointer;
+    return true;
+}
 constexpr unsigned kMaxDepth = 32;
 constexpr unsigned kStateRing = kMaxDepth + 3;      // FxStreamState records per stream: one per block in flight and then some
 constexpr uint32_t kFallbackWaves = 32;             // in-chain launch for frames the batch Viterbi path hands back (normally none)
@@ -331,11 +344,20 @@ static int make_slot(fxrx_ctx_s *c)
 
 static void sync_all(fxrx_ctx_s *c) { if (c->st_chain) (void)hipStreamSynchronize(c->st_chain); for (auto &s : c->slots) if (s->st) (void)hipStreamSynchronize(s->st); }
 
+// FXRX_DEBUG_SUBMIT_PROFILE: where the host time of fxrx_submit goes (printed when a context is destroyed)
+static double g_prof[8]; static unsigned long g_prof_n;
+static const bool g_prof_on = std::getenv("FXRX_DEBUG_SUBMIT_PROFILE") != nullptr;
+static inline double prof_now() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 void fxrx_destroy(fxrx_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->cfg.device);
     sync_all(c);
+    if (g_prof_on && g_prof_n) {
+        std::fprintf(stderr, "[fxrx] submit profile over %lu blocks (ms per block): upload + bookkeeping %.4f, segments %.4f, memory + descriptors %.4f, front launches %.4f, back launches %.4f\n",
+                     g_prof_n, g_prof[0] / g_prof_n, g_prof[1] / g_prof_n, g_prof[2] / g_prof_n, g_prof[3] / g_prof_n, g_prof[4] / g_prof_n);
+        for (auto &v : g_prof) v = 0.0; g_prof_n = 0;
+    }
     for (auto &s : c->slots) {
         for (auto e : s->ev) if (e) (void)hipEventDestroy(e);
         if (s->st) (void)hipStreamDestroy(s->st);
@@ -451,6 +473,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     const bool detect = c->cfg.mode == FXRX_MODE_DETECTOR;
     const uint64_t b = sl.seq;
     hipStream_t st = sl.st;
+    const double tp0 = g_prof_on ? prof_now() : 0.0;
 
     // ---- 1. segments ----
     uint64_t seg = c->cfg.segment_len;
@@ -571,6 +594,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     }
     if (sl.sym_cap >= (1ull << 32) || sl.dw_cap >= (1ull << 32)) { set_err("fxrx_submit: batch too large for 32-bit arena offsets"); return FXRX_ERR_ARG; }
 
+    const double tp1 = g_prof_on ? prof_now() : 0.0;
     // ---- 2. memory ----
     auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
     const size_t o_list = up16(NJ * sizeof(FxWalkJob)), o_streams = o_list + up16(NJ * sizeof(uint32_t)), desc_bytes = o_streams + up16(NS * sizeof(FxStreamDesc));
@@ -602,8 +626,9 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     const uint32_t *d_list = reinterpret_cast<const uint32_t *>(sl.d_desc.p + o_list);
     const unsigned mode = detect ? FX_MODE_DETECT : FX_MODE_FLEXRX;
 
+    const double tp2 = g_prof_on ? prof_now() : 0.0;
     // ---- 3. the chain, front part: walkers and seek verification ----
-    HIP_OK(hipMemcpyAsync(sl.d_desc.p, sl.hp_desc.p, desc_bytes, hipMemcpyHostToDevice, st));
+    HIP_OK(fx_launch_upload(st, sl.hp_desc.p, sl.d_desc.p, desc_bytes, (unsigned)c->n_cus));     // (descriptors: our own page-locked buffer)
     const int tl = c->timing_level >= 0 ? c->timing_level : (c->depth > 1 ? 0 : 2);      // stage events: see fxrx_set_timing
     sl.timing_level = tl;
     for (int rep = 0; rep < c->debug_walk_twice; rep++)
@@ -617,7 +642,7 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     hipStream_t cst = st;                                     // the stream the rest of the front part and the chain kernel go to
     if (!late.empty()) {
         if (verify) {
-            HIP_OK(hipMemcpyAsync(&sl.d_hdr.p->runs_done, &sl.d_hdr.p->n_runs, sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            HIP_OK(fx_launch_copy_u32(st, &sl.d_hdr.p->n_runs, &sl.d_hdr.p->runs_done));
             HIP_OK(fx_launch_seekverify(c->verify_per_cu * (unsigned)c->n_cus, st, sl.d_runs.p, sl.run_cap, d_jobs, sl.d_wres.p, sl.d_frames.p, sl.d_hdr.p, c->d_tables, 0u));
         }
         // (from here to the chain kernel the block is on the chain of dependencies that runs through all blocks of a continuing
@@ -643,7 +668,10 @@ static int enqueue_block(fxrx_ctx_s *c, Slot &sl)
     // carry[(b + 1) % 3], which the payload MF of block b - 2 may still be reading
     if (late.empty() && c->prev_chain) HIP_OK(hipStreamWaitEvent(cst, c->prev_chain, 0));
     if (c->carry_reader[(b + 1) % 3]) HIP_OK(hipStreamWaitEvent(cst, c->carry_reader[(b + 1) % 3], 0));
-    return enqueue_back(c, sl, kChainFast, cst);
+    const double tp3 = g_prof_on ? prof_now() : 0.0;
+    const int rb = enqueue_back(c, sl, kChainFast, cst);
+    if (g_prof_on) { const double tp4 = prof_now(); g_prof[1] += tp1 - tp0; g_prof[2] += tp2 - tp1; g_prof[3] += tp3 - tp2; g_prof[4] += tp4 - tp3; g_prof_n++; }
+    return rb;
 }
 
 // ---- back part of the chain: chain kernel, plan, payload stage.  `full`: the full-size chain kernel, which can walk
@@ -793,7 +821,13 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
         if (on_device) sl.x[s] = (const float2 *)iq[s];
         else {
             if (sl.d_in[s].reserve(nn + 1)) return FXRX_ERR_HIP;
-            if (nn) HIP_OK(hipMemcpyAsync(sl.d_in[s].p, iq[s], nn * sizeof(float2), hipMemcpyHostToDevice, sl.st));
+            if (nn) {
+                // page-locked source, moderate size: the shader cores fetch it (fx_upload_kernel: the launch costs microseconds, the
+                // copy call held this thread for hundreds); pageable memory and very large blocks go through the runtime's copy engines
+                const void *dsrc = nullptr;
+                if (nn * sizeof(float2) <= kUploadKernelMax && pinned_device_ptr(iq[s], &dsrc)) HIP_OK(fx_launch_upload(sl.st, dsrc, sl.d_in[s].p, nn * sizeof(float2), (unsigned)c->n_cus));
+                else HIP_OK(hipMemcpyAsync(sl.d_in[s].p, iq[s], nn * sizeof(float2), hipMemcpyHostToDevice, sl.st));
+            }
             sl.x[s] = sl.d_in[s].p;
         }
         sl.snap[s].tot0 = S.total; sl.snap[s].fresh_start = S.fresh_start; sl.snap[s].carry_bound = S.fresh_start ? 0 : S.carry_bound;
@@ -807,6 +841,7 @@ int fxrx_submit(fxrx_ctx *c, const void *const *iq, const uint64_t *n_samples, i
     sl.dbg_submit_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count() - c->ref_host_ms;
     sl.timing.samples = total_new;
     if (c->debug_fail_submit) { c->debug_fail_submit--; set_err("fxrx_submit: injected failure (fxrx_debug_fail)"); return FXRX_ERR_STATE; }
+    if (g_prof_on) g_prof[0] += prof_now() - std::chrono::duration<double, std::milli>(t_enter.time_since_epoch()).count();
     int r = enqueue_block(c, sl);
     if (r) return r;
     undo.armed = false;

@@ -3856,6 +3856,39 @@ void fx_symcopy_kernel(const FxBlockHdr *hdr, const float2 *sym, float2 *host)
     const uint4 *src = reinterpret_cast<const uint4 *>(sym); uint4 *dst = reinterpret_cast<uint4 *>(host);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
 }
+// ---- uploads as kernels.  A block's samples in page-locked host memory (the drop-in's ring, a caller's pinned buffer) and the
+// block's own descriptors are read over the bus by the shader cores: a launch costs the host 3 us, where hipMemcpyAsync held the
+// calling thread for 0.2 - 0.6 ms per 8-MB block (more with more blocks in flight) and 30 - 50 us per small copy -- with 2^20-sample
+// blocks of one continuing stream the host was what limited the rate.  8-byte pieces (a float2), eight in flight per thread.
+extern "C" __global__ __launch_bounds__(256)
+void fx_upload_kernel(const unsigned long long *src, unsigned long long *dst, size_t n8)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 7 * stride < n8; i += 8 * stride) {
+        unsigned long long v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = __builtin_nontemporal_load(src + i + k * stride);
+#pragma unroll
+        for (int k = 0; k < 8; k++) dst[i + k * stride] = v[k];
+    }
+    for (; i < n8; i += stride) dst[i] = __builtin_nontemporal_load(src + i);
+}
+extern "C" hipError_t fx_launch_upload(hipStream_t st, const void *src, void *dst, size_t bytes, unsigned n_cus)
+{
+    const size_t n8 = (bytes + 7) / 8;
+    if (n8 == 0) return hipSuccess;
+    const unsigned grid = (unsigned)std::min<size_t>((n8 + 256 * 8 - 1) / (256 * 8), 4u * (size_t)n_cus);
+    hipLaunchKernelGGL(fx_upload_kernel, dim3(grid ? grid : 1u), dim3(256), 0, st, reinterpret_cast<const unsigned long long *>(src), reinterpret_cast<unsigned long long *>(dst), n8);
+    return hipGetLastError();
+}
+extern "C" __global__ void fx_copy_u32_kernel(const uint32_t *src, uint32_t *dst) { *dst = *src; }
+extern "C" hipError_t fx_launch_copy_u32(hipStream_t st, const uint32_t *src, uint32_t *dst)
+{
+    hipLaunchKernelGGL(fx_copy_u32_kernel, dim3(1), dim3(1), 0, st, src, dst);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t fx_launch_symcopy(unsigned grid, hipStream_t st, const FxBlockHdr *hdr, const float2 *sym, float2 *host)
 {
     hipLaunchKernelGGL(fx_symcopy_kernel, dim3(grid), dim3(256), 0, st, hdr, sym, host);
