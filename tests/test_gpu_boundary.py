@@ -174,3 +174,26 @@ def test_two_flexframesync_handles_on_two_threads(fx, oracle):
     for t in th: t.join()
     for t in range(2):
         compare_frames(ofs[t], res[t])
+
+
+def test_pinned_host_blocks_take_the_upload_kernel_and_give_the_same_frames(fx, oracle):
+    """Host blocks in page-locked memory are fetched by fx_upload_kernel (fx_host.cpp: pinned_device_ptr), pageable ones by the
+    runtime's copy: both must give what the same samples give when they are resident on the device -- odd lengths, a block that
+    starts at an odd sample of the pinned allocation, consecutive blocks of one stream."""
+    import torch
+    x, _ = fx.synth_stream(333_333, stream_id=317, payload_len=120)
+    of = [_okey(f) for f in oracle_frames(oracle, x)]
+    xp = torch.from_numpy(np.concatenate([np.zeros(1, np.complex64), x])).pin_memory()      # the stream starts 8 bytes into the allocation
+    base = xp.data_ptr() + 8
+    cuts = [0, 100_001, 250_000, len(x)]
+    for on_pinned in (True, False):
+        ctx = fx.RxContext(1)
+        ctx.set_depth(2)
+        got = []
+        for a, b in zip(cuts, cuts[1:]):
+            if on_pinned: ctx.submit_raw([base + 8 * a], [b - a], False)
+            else:
+                blk = np.ascontiguousarray(x[a:b]); ctx.submit_raw([blk.ctypes.data], [b - a], False)
+            got += [_key(g) for g in ctx.results(ctx.collect_raw())]
+        assert got == of and len(of) > 10
+        ctx.close()

@@ -6,9 +6,11 @@ import importlib, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+cont = "--continuous" in sys.argv                       # the passes as consecutive blocks of one stream (no reset between them)
+if cont: sys.argv.remove("--continuous")
 if len(sys.argv) < 2:
     for stop in ("4", "5", "6", "0"):
-        subprocess.run([sys.executable, os.path.abspath(__file__), stop], env=dict(os.environ, FXRX_DEBUG_STOP_AFTER=stop))
+        subprocess.run([sys.executable, os.path.abspath(__file__), stop] + (["--continuous"] if cont else []), env=dict(os.environ, FXRX_DEBUG_STOP_AFTER=stop))
     sys.exit(0)
 import torch
 fx = importlib.import_module("gr-liquiddsp_amd")
@@ -26,8 +28,8 @@ def run(k):
     for _ in range(k):
         if infl == depth:
             t = time.perf_counter(); ctx.collect_raw(); acc[0] += time.perf_counter() - t; infl -= 1
-        ctx.reset()
+        if not cont: ctx.reset()
         t = time.perf_counter(); ctx.submit_raw(ptrs, counts, True); acc[1] += time.perf_counter() - t; acc[2] += 1; infl += 1
     while infl: ctx.collect_raw(); infl -= 1
 run(100); torch.cuda.synchronize(); acc[:] = [0.0, 0.0, 0]; t0 = time.perf_counter(); run(1500); torch.cuda.synchronize()
-print("stop after %s: %.4f ms per block (host: %.4f ms in collect, %.4f ms in submit per block)" % (sys.argv[1], (time.perf_counter() - t0) / 1500 * 1e3, acc[0] / acc[2] * 1e3, acc[1] / acc[2] * 1e3), flush=True)
+print(("continuing stream, " if cont else "") + "stop after %s: %.4f ms per block (host: %.4f ms in collect, %.4f ms in submit per block)" % (sys.argv[1], (time.perf_counter() - t0) / 1500 * 1e3, acc[0] / acc[2] * 1e3, acc[1] / acc[2] * 1e3), flush=True)
