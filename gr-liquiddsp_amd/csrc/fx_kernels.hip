@@ -1449,9 +1449,13 @@ __device__ __forceinline__ void wg_sync_global() { __threadfence(); __syncthread
 
 __device__ __forceinline__ void copy_frame(FxFrame *dst, const FxFrame *src)
 {
-    const uint2 *a = reinterpret_cast<const uint2 *>(src); uint2 *b = reinterpret_cast<uint2 *>(dst);
-#pragma unroll
-    for (int i = 0; i < (int)(sizeof(FxFrame) / 8); i++) b[i] = a[i];
+    // (frame tables are 256-byte records at 256-byte boundaries: sixteen 16-byte pieces, all loads in flight before the first store)
+    const uint4 *a = reinterpret_cast<const uint4 *>(src); uint4 *b = reinterpret_cast<uint4 *>(dst);
+    static_assert(sizeof(FxFrame) == 256, "sixteen 16-byte pieces");
+    const uint4 v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = a[4], v5 = a[5], v6 = a[6], v7 = a[7];
+    const uint4 v8 = a[8], v9 = a[9], v10 = a[10], v11 = a[11], v12 = a[12], v13 = a[13], v14 = a[14], v15 = a[15];
+    b[0] = v0; b[1] = v1; b[2] = v2; b[3] = v3; b[4] = v4; b[5] = v5; b[6] = v6; b[7] = v7;
+    b[8] = v8; b[9] = v9; b[10] = v10; b[11] = v11; b[12] = v12; b[13] = v13; b[14] = v14; b[15] = v15;
 }
 
 // Fast path of the chain (nothing to repair, at most CHAIN_MAXJ segments): returns false when the general path is needed.
@@ -1475,6 +1479,7 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
     const uint32_t first = sd.first_job, nj = sd.n_jobs, T = nj;           // T: the list's end marker
     if (nj > CHAIN_MAXJ) return false;
     if (tid < 8) C.sh[tid] = 0;
+    const unsigned long long tph_ = __builtin_readcyclecounter();      // phase clocks of stream 0 (fxrx_debug_chain_stamps): [4] look-ups, [5] list ranking
     __syncthreads();
     // A.
     for (uint32_t j = tid; j < nj; j += NT) {
@@ -1520,6 +1525,7 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
         C.lk[j] = lk; C.skip[j] = (uint16_t)skipE; C.m[j] = 0xFFFFu; C.pred[j] = 0xFFFFu;
     }
     __syncthreads();
+    if (hdr_rw && blockIdx.x == 0 && tid == 0) hdr_rw->stamp[4] = (uint32_t)(__builtin_readcyclecounter() - tph_);
     // B. list ranking.  Edge j -> nxt carries the number of frames nxt contributes when entered from j.
     for (uint32_t j = tid; j <= nj; j += NT) {
         uint32_t jmp = T, w = 0;
@@ -1589,7 +1595,10 @@ __device__ __forceinline__ bool chain_fast_path(const FxStreamDesc &sd, const Fx
         if (tid == 0 && !C.sh[0] && C.sh[3] > sd.chain_cap) { C.sh[0] = 1; C.sh[5] = 1; }
         __syncthreads();
     }
-    // C.
+    if (hdr_rw && blockIdx.x == 0 && tid == 0) hdr_rw->stamp[5] = (uint32_t)(__builtin_readcyclecounter() - tph_);
+    // C. compaction, a thread per segment on the chain.  (Tried: the segments' threads only list the chain's frames and the waves copy
+    // them, a 256-byte record per coalesced load / store pair -- three times slower: four waves keep sixteen records in flight, 256
+    // threads with sixteen 16-byte loads each keep thousands.)
     if (!C.sh[0]) {
         for (uint32_t j = tid; j < nj; j += NT) {
             const uint32_t cm = C.m[j];

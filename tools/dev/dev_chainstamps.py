@@ -11,5 +11,5 @@ for it in range(3):
 out = (C.c_uint32 * 8)()
 fx.lib().fxrx_debug_chain_stamps(ctx.h, C.byref(out))
 tm = ctx.timing()
-print("chain+plan %.3f ms; chainfast cycles: fast path %d, pointer chase %d, kernel total %d (jobs %d, frames %d)" % (tm["chain_ms"], out[0], out[2], out[3], tm["walk_jobs"], tm["frames"]))
+print("chain+plan %.3f ms; chainfast cycles: look-ups %d, + list ranking %d, + compaction = fast path %d, kernel total %d (jobs %d, frames %d)" % (tm["chain_ms"], out[4], out[5], out[0], out[3], tm["walk_jobs"], tm["frames"]))
 print({k: round(v, 4) for k, v in tm.items() if k.endswith("_ms")})
